@@ -1,0 +1,366 @@
+"""CPU oracle for the variational optical-flow hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy/scipy restatement of the algorithm of the reference's
+``source/optical_flow.py::variational_optical_flow`` (OF.py:715-1210).  It is the checker for
+the HIP solver: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  The product path (``opticalflow_amd/``) never does.
+
+Parity pinning: the restatement is checked entry-for-entry / value-for-value against outputs of
+the reference itself (imported in the build container through its own ``use_direct_solver=True``
+branch) by ``tests/golden/make_golden.py``; the resulting fixtures live in ``tests/golden/*.npz``
+and are re-checked on CPU by ``tests/test_oracle_golden.py``.
+
+Index convention (OF.py:1291-1300): unknown ``q`` of pixel ``(i, j)`` has global index
+``3*N_j*i + 3*j + q`` with ``q = 0: ux, 1: uy, 2: remodelling (gamma)``; axis 0 is "x".
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.ndimage
+import scipy.sparse
+import scipy.sparse.linalg
+
+__all__ = [
+    "make_fake_data_frame", "make_gaussian_stack", "make_texture_stack", "blur_movie",
+    "derivatives", "assemble_system", "apply_constant_boundary_condition", "functionals",
+    "solve_pair_direct", "variational_optical_flow", "apply_operator_interior",
+    "rhs_interior", "interior_to_full", "relative_residual",
+]
+
+
+# --------------------------------------------------------------------------------------
+# synthetic data
+# --------------------------------------------------------------------------------------
+def make_fake_data_frame(x_position, y_position, sigma=1.0, width=20.0, include_noise=False,
+                         dimension=1000):
+    """Gaussian hat ``exp((-(x-x0)^2 - (y-y0)^2)/sigma^2)`` on ``linspace(0, width, dimension)^2``.
+
+    Follows OF.py:376-423 (the double loop at 415-417 is evaluated as a broadcast; the
+    expression per pixel is kept in the same operation order so results are bit-identical).
+    Returns ``(frame, delta_x)``.
+    """
+    x = np.linspace(0, width, dimension)
+    y = np.linspace(0, width, dimension)
+    frame = np.exp((-(x[:, None] - x_position) ** 2 - (y[None, :] - y_position) ** 2) / sigma ** 2)
+    delta_x = x[1] - x[0]
+    if include_noise:  # OF.py:419-421
+        frame = frame + np.random.rand(dimension, dimension) * 0.0000001
+        frame = np.abs(frame)
+    return frame, delta_x
+
+
+def make_gaussian_stack(dimension=128, n_frames=8, sigma=3.0, width=5.0, v=(0.1, 0.2),
+                        remodelling_rate=0.05):
+    """BASELINE config 1 ("translating Gaussian"): the AVOF.py:29-31 construction extended in
+    time: frame t = hat centred at (2.5 + v_x t, 2.5 + v_y t) + remodelling_rate * t."""
+    frames = []
+    delta_x = None
+    for t in range(n_frames):
+        f, delta_x = make_fake_data_frame(width / 2 + v[0] * t, width / 2 + v[1] * t, sigma=sigma,
+                                          width=width, dimension=dimension)
+        frames.append(f + remodelling_rate * t)
+    return np.stack(frames), delta_x
+
+
+def texture_parameters(n, seed, n_modes=64):
+    """Random Fourier-mode parameters of the "actin-like texture" (SURVEY.md section 8(d), C2)."""
+    rng = np.random.default_rng(seed)
+    fm = max(2, n // 16)
+    f = rng.integers(-fm, fm + 1, n_modes)
+    g = rng.integers(-fm, fm + 1, n_modes)
+    a = rng.random(n_modes) + 0.5
+    phi = 2 * np.pi * rng.random(n_modes)
+    return f.astype(np.float64), g.astype(np.float64), a, phi
+
+
+def make_texture_stack(n, n_frames, seed=0, n_modes=64, shift=(0.3, 0.6), first_frame=0):
+    """Exactly translating band-limited texture in [0, 1]; true flow ``shift`` px/frame, gamma = 0.
+
+    ``A_t(i,j) = sum_k a_k cos(2 pi (f_k (i - sx t) + g_k (j - sy t))/n + phi_k)``,
+    ``I_t = clip(0.5 + 0.45 A_t sqrt(K) / (3 sum a_k), 0, 1)``.
+    """
+    f, g, a, phi = texture_parameters(n, seed, n_modes)
+    i = np.arange(n, dtype=np.float64)
+    out = np.empty((n_frames, n, n))
+    scale = 0.45 * np.sqrt(n_modes) / (3.0 * a.sum())
+    for t in range(n_frames):
+        tt = first_frame + t
+        # separable evaluation: cos(p_i + q_j) = cos p cos q - sin p sin q
+        pi_ = 2 * np.pi * f[:, None] * (i[None, :] - shift[0] * tt) / n + phi[:, None]   # (K, n)
+        qj = 2 * np.pi * g[:, None] * (i[None, :] - shift[1] * tt) / n                  # (K, n)
+        A = (a[:, None] * np.cos(pi_)).T @ np.cos(qj) - (a[:, None] * np.sin(pi_)).T @ np.sin(qj)
+        out[t] = np.clip(0.5 + scale * A, 0.0, 1.0)
+    return out
+
+
+def blur_movie(movie, smoothing_sigma):
+    """Per-frame Gaussian blur, OF.py:282-306.  ``skimage.filters.gaussian(frame, sigma,
+    preserve_range=True)`` on a float64 2-D frame is ``scipy.ndimage.gaussian_filter(frame,
+    sigma, mode='nearest', truncate=4.0)`` (skimage's defaults: mode='nearest', truncate=4.0)."""
+    movie = np.asarray(movie)
+    out = np.zeros_like(movie, dtype=np.float64)
+    for k in range(movie.shape[0]):
+        out[k] = scipy.ndimage.gaussian_filter(movie[k].astype(np.float64), smoothing_sigma,
+                                               mode="nearest", truncate=4.0)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# derivatives, OF.py:676-713 and 812-827
+# --------------------------------------------------------------------------------------
+def derivatives(I, J, reference_quirks=True):
+    """Interior ``(N_i-2, N_j-2)`` derivative fields of the frame pair (I = previous, J = current).
+
+    ``reference_quirks=True`` reproduces OF.py:698-699 where rule 'dy' returns the x-derivative,
+    so ``Dy == Dx`` (used at OF.py:813).  ``Dyt`` (OF.py:818-819) is a genuine axis-1 difference.
+    """
+    d = {}
+    d["P"] = I[1:-1, 1:-1]
+    d["Dx"] = (I[2:, 1:-1] - I[:-2, 1:-1]) / 2
+    d["Dy"] = d["Dx"] if reference_quirks else (I[1:-1, 2:] - I[1:-1, :-2]) / 2
+    d["Dxt"] = (J[2:, 1:-1] - J[:-2, 1:-1] - I[2:, 1:-1] + I[:-2, 1:-1]) / 2
+    d["Dyt"] = (J[1:-1, 2:] - J[1:-1, :-2] - I[1:-1, 2:] + I[1:-1, :-2]) / 2
+    d["Dt"] = (J - I)[1:-1, 1:-1]
+    d["Dxx"] = I[2:, 1:-1] + I[:-2, 1:-1] - 2 * I[1:-1, 1:-1]
+    d["Dyy"] = I[1:-1, 2:] + I[1:-1, :-2] - 2 * I[1:-1, 1:-1]
+    d["Dxy"] = (I[2:, 2:] - I[2:, :-2] - I[:-2, 2:] + I[:-2, :-2]) / 4
+    return d
+
+
+def _interior_stencil(d, alpha, beta):
+    """List of ``(row_q, di, dj, col_q, coefficient array)`` for interior rows, OF.py:843-962."""
+    P, Dx, Dy, Dxx, Dyy, Dxy = d["P"], d["Dx"], d["Dy"], d["Dxx"], d["Dyy"], d["Dxy"]
+    one = np.ones_like(P)
+    PP4 = P * P / 4
+    st = [
+        # ux row (OF.py:843-887)
+        (0, 0, 0, 0, P * (Dxx + -2 * P) - 4 * alpha),
+        (0, 0, 0, 1, P * Dxy),
+        (0, -1, 0, 0, P * (-Dx + P) + alpha),
+        (0, +1, 0, 0, P * (+Dx + P) + alpha),
+        (0, 0, -1, 0, alpha * one),
+        (0, 0, +1, 0, alpha * one),
+        (0, 0, -1, 1, P * (-Dx) / 2),
+        (0, 0, +1, 1, P * (+Dx) / 2),
+        (0, -1, 0, 1, P * (-Dy) / 2),
+        (0, +1, 0, 1, P * (+Dy) / 2),
+        (0, -1, -1, 1, PP4),
+        (0, +1, +1, 1, PP4),
+        (0, -1, +1, 1, -P * P / 4),
+        (0, +1, -1, 1, -P * P / 4),
+        (0, -1, 0, 2, P / 2),
+        (0, +1, 0, 2, -P / 2),
+        # uy row (OF.py:892-936)
+        (1, 0, 0, 1, P * (Dyy + -2 * P) - 4 * alpha),
+        (1, 0, 0, 0, P * Dxy),
+        (1, 0, -1, 1, P * (-Dy + P) + alpha),
+        (1, 0, +1, 1, P * (+Dy + P) + alpha),
+        (1, -1, 0, 1, alpha * one),
+        (1, +1, 0, 1, alpha * one),
+        (1, -1, 0, 0, P * (-Dy) / 2),
+        (1, +1, 0, 0, P * (+Dy) / 2),
+        (1, 0, -1, 0, P * (-Dx) / 2),
+        (1, 0, +1, 0, P * (+Dx) / 2),
+        (1, -1, -1, 0, PP4),
+        (1, +1, +1, 0, PP4),
+        (1, -1, +1, 0, -P * P / 4),
+        (1, +1, -1, 0, -P * P / 4),
+        (1, 0, -1, 2, P / 2),
+        (1, 0, +1, 2, -P / 2),
+        # gamma row (OF.py:942-960)
+        (2, 0, 0, 2, (-1 - 4 * beta) * one),
+        (2, 0, 0, 0, Dx),
+        (2, 0, 0, 1, Dy),
+        (2, -1, 0, 2, beta * one),
+        (2, +1, 0, 2, beta * one),
+        (2, 0, -1, 2, beta * one),
+        (2, 0, +1, 2, beta * one),
+        (2, -1, 0, 0, -P / 2),
+        (2, +1, 0, 0, P / 2),
+        (2, 0, -1, 1, -P / 2),
+        (2, 0, +1, 1, P / 2),
+    ]
+    return st
+
+
+def assemble_system(I, J, alpha, beta, reference_quirks=True):
+    """Sparse system ``A x = b`` of one frame pair exactly as OF.py:833-1072 builds it.
+
+    Returns ``(A_csr, b)`` with ``A`` of shape ``(3 N_i N_j,)*2``.  Boundary rows follow
+    OF.py:964-1070: the top/bottom index sets (all j) and left/right index sets (all i) overlap
+    at the corners, and because ``lil_matrix`` assignment *sets* entries the corner rows end up
+    as ``x(0,0) - x(2,0) - x(0,2) = 0``.
+    """
+    I = np.asarray(I, dtype=np.float64)
+    J = np.asarray(J, dtype=np.float64)
+    N_i, N_j = I.shape
+    d = derivatives(I, J, reference_quirks)
+    ii, jj = np.meshgrid(np.arange(1, N_i - 1), np.arange(1, N_j - 1), indexing="ij")
+    rows, cols, vals = [], [], []
+    for (rq, di, dj, cq, coef) in _interior_stencil(d, alpha, beta):
+        rows.append((3 * N_j * ii + 3 * jj + rq).ravel())
+        cols.append((3 * N_j * (ii + di) + 3 * (jj + dj) + cq).ravel())
+        vals.append(np.broadcast_to(coef, ii.shape).ravel())
+    # boundary rows: diagonal 1 (set, not summed -> emit once per boundary unknown)
+    bmask = np.zeros((N_i, N_j), dtype=bool)
+    bmask[0, :] = bmask[-1, :] = True
+    bmask[:, 0] = bmask[:, -1] = True
+    bi, bj = np.nonzero(bmask)
+    for q in range(3):
+        r = 3 * N_j * bi + 3 * bj + q
+        rows.append(r); cols.append(r); vals.append(np.ones(r.size))
+    jall = np.arange(N_j)
+    iall = np.arange(N_i)
+    for q in range(3):
+        # top (OF.py:965-972): x(0,j) - x(2,j)
+        r = 3 * jall + q
+        rows.append(r); cols.append(r + 6 * N_j); vals.append(-np.ones(N_j))
+        # bottom (OF.py:1009-1016): x(N_i-1,j) - x(N_i-3,j)
+        r = 3 * N_j * (N_i - 1) + 3 * jall + q
+        rows.append(r); cols.append(r - 6 * N_j); vals.append(-np.ones(N_j))
+        # left (OF.py:1053-1060): x(i,0) - x(i,2)
+        r = 3 * N_j * iall + q
+        rows.append(r); cols.append(r + 6); vals.append(-np.ones(N_i))
+        # right (OF.py:1063-1070): x(i,N_j-1) - x(i,N_j-3)
+        r = 3 * N_j * iall + 3 * (N_j - 1) + q
+        rows.append(r); cols.append(r - 6); vals.append(-np.ones(N_i))
+    rows = np.concatenate(rows); cols = np.concatenate(cols); vals = np.concatenate(vals)
+    n = 3 * N_i * N_j
+    A = scipy.sparse.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    b = np.zeros(n)
+    base = (3 * N_j * ii + 3 * jj).ravel()
+    b[base + 0] = (-d["P"] * d["Dxt"]).ravel()   # OF.py:889
+    b[base + 1] = (-d["P"] * d["Dyt"]).ravel()   # OF.py:938
+    b[base + 2] = (-d["Dt"]).ravel()             # OF.py:962
+    return A, b
+
+
+# --------------------------------------------------------------------------------------
+# post-processing, OF.py:1159-1205 and 1304-1316
+# --------------------------------------------------------------------------------------
+def apply_constant_boundary_condition(image):
+    """In-place mirror fix-up, rows first then columns (OF.py:1313-1316)."""
+    image[0, :] = image[2, :]
+    image[-1, :] = image[-3, :]
+    image[:, 0] = image[:, 2]
+    image[:, -1] = image[:, -3]
+
+
+def _dx(m):
+    return (m[2:, 1:-1] - m[:-2, 1:-1]) / 2
+
+
+def _dy(m, reference_quirks=True):
+    return _dx(m) if reference_quirks else (m[1:-1, 2:] - m[1:-1, :-2]) / 2
+
+
+def functionals(I, J, v_x, v_y, gamma, alpha, beta, reference_quirks=True):
+    """``(L1, speed, remodelling)`` functionals of one pair on BC-fixed fields (OF.py:1167-1183).
+    Velocities in pixels/frame."""
+    d = derivatives(I, J, reference_quirks)
+    dvx_dx, dvx_dy = _dx(v_x), _dy(v_x, reference_quirks)
+    dvy_dx, dvy_dy = _dx(v_y), _dy(v_y, reference_quirks)
+    dg_dx, dg_dy = _dx(gamma), _dy(gamma, reference_quirks)
+    L1 = np.sum(np.power(d["Dt"] + v_x[1:-1, 1:-1] * d["Dx"] + v_y[1:-1, 1:-1] * d["Dy"]
+                         + d["P"] * dvx_dx + d["P"] * dvy_dy - gamma[1:-1, 1:-1], 2))
+    speed = alpha * np.sum(np.power(dvx_dx, 2) + np.power(dvx_dy, 2)
+                           + np.power(dvy_dx, 2) + np.power(dvy_dy, 2))
+    rem = beta * np.sum(np.power(dg_dx, 2) + np.power(dg_dy, 2))
+    return float(L1), float(speed), float(rem)
+
+
+def solve_pair_direct(I, J, alpha, beta, reference_quirks=True):
+    """Direct solution of one pair: returns the raw ``(v_x, v_y, gamma)`` full-grid planes
+    (before the mirror fix-up), the relative residual and ``(A, b)``."""
+    A, b = assemble_system(I, J, alpha, beta, reference_quirks)
+    x = scipy.sparse.linalg.spsolve(A.tocsr(), b)          # OF.py:1147
+    relres = np.linalg.norm(A @ x - b) / np.linalg.norm(b)  # OF.py:1151
+    N_i, N_j = I.shape
+    x3 = x.reshape(N_i, N_j, 3)
+    return x3[:, :, 0].copy(), x3[:, :, 1].copy(), x3[:, :, 2].copy(), relres, (A, b)
+
+
+def variational_optical_flow(movie, delta_x=1.0, delta_t=1.0, speed_alpha=1.0,
+                             remodelling_alpha=1000.0, smoothing_sigma=None, initial_v_x=0.0,
+                             initial_v_y=0.0, initial_remodelling=0.0, use_direct_solver=True,
+                             reference_quirks=True, return_stats=False):
+    """Oracle restatement of OF.py:715-1210 with the direct solve (the reference's own
+    ``use_direct_solver=True`` branch, OF.py:1146-1147).  The initial fields do not influence a
+    direct solve; they are accepted for signature parity."""
+    movie = np.asarray(movie).astype(np.float64)                      # OF.py:769
+    mta = blur_movie(movie, smoothing_sigma) if smoothing_sigma is not None else movie
+    T, N_i, N_j = movie.shape
+    all_v_x = np.zeros((T - 1, N_i, N_j)); all_v_y = np.zeros((T - 1, N_i, N_j))
+    all_g = np.zeros((T - 1, N_i, N_j))
+    L1 = np.zeros(T); SP = np.zeros(T); RM = np.zeros(T); relres = np.zeros(T - 1)
+    for k in range(1, T):
+        I, J = mta[k - 1], mta[k]
+        vx, vy, g, rr, _ = solve_pair_direct(I, J, speed_alpha, remodelling_alpha, reference_quirks)
+        relres[k - 1] = rr
+        for f in (vx, vy, g):
+            apply_constant_boundary_condition(f)                       # OF.py:1164-1166
+        all_v_x[k - 1], all_v_y[k - 1], all_g[k - 1] = vx, vy, g
+        L1[k], SP[k], RM[k] = functionals(I, J, vx, vy, g, speed_alpha, remodelling_alpha,
+                                          reference_quirks)
+    all_v_x *= delta_x / delta_t                                        # OF.py:1189-1191
+    all_v_y *= delta_x / delta_t
+    result = dict(v_x=all_v_x, v_y=all_v_y, speed=np.sqrt(all_v_x ** 2 + all_v_y ** 2),
+                  remodelling=all_g, original_data=movie, delta_x=delta_x, delta_t=delta_t,
+                  blurred_data=mta, converged=True, L1_functional=np.sum(L1),
+                  remodelling_functional=np.sum(RM),
+                  # OF.py:1205 assigns the remodelling sum to 'speed_functional' (reference bug)
+                  speed_functional=np.sum(RM) if reference_quirks else np.sum(SP))
+    if return_stats:
+        result["_relres"] = relres
+        result["_true_speed_functional"] = np.sum(SP)
+    return result
+
+
+# --------------------------------------------------------------------------------------
+# matrix-free operator on the interior grid (boundary unknowns eliminated)
+# --------------------------------------------------------------------------------------
+def _fold(n):
+    """Index map for the ghost ring of an interior axis of length n: ghost -1 -> 1, ghost n -> n-2
+    (x(0,.) = x(2,.), x(N-1,.) = x(N-3,.) in full-grid indices; OF.py:965-972,1009-1016)."""
+    idx = np.arange(-1, n + 1)
+    idx[0] = 1
+    idx[-1] = n - 2
+    return idx
+
+
+def interior_to_full(xi):
+    """Interior planes ``(..., n_i, n_j)`` -> RAW full-grid planes ``(..., n_i+2, n_j+2)``
+    satisfying the reference's boundary rows: edges mirror the second-next line, corners are the
+    sum of their two edge partners (= 2 * x(2,2)), SURVEY.md Appendix A.4."""
+    n_i, n_j = xi.shape[-2:]
+    g = xi[..., _fold(n_i), :][..., :, _fold(n_j)].copy()
+    for ci in (0, -1):
+        for cj in (0, -1):
+            g[..., ci, cj] *= 2.0
+    return g
+
+
+def apply_operator_interior(I, x, alpha, beta, reference_quirks=True):
+    """``A_int x`` for interior unknowns ``x`` of shape ``(3, n_i, n_j)``: the interior rows of
+    the reference system (OF.py:843-962) with the boundary unknowns substituted from the
+    boundary rows (OF.py:964-1070)."""
+    d = derivatives(I, I, reference_quirks)
+    g = interior_to_full(np.asarray(x))
+    n_i, n_j = x.shape[-2:]
+    out = np.zeros((3, n_i, n_j))
+    for (rq, di, dj, cq, coef) in _interior_stencil(d, alpha, beta):
+        out[rq] += coef * g[cq, 1 + di:1 + di + n_i, 1 + dj:1 + dj + n_j]
+    return out
+
+
+def rhs_interior(I, J, reference_quirks=True):
+    d = derivatives(I, J, reference_quirks)
+    return np.stack([-d["P"] * d["Dxt"], -d["P"] * d["Dyt"], -d["Dt"]])
+
+
+def relative_residual(I, J, v_x, v_y, gamma, alpha, beta, reference_quirks=True):
+    """Independent ``||A x - b|| / ||b||`` (OF.py:1151) of RAW full-grid planes, through the
+    assembled matrix."""
+    A, b = assemble_system(I, J, alpha, beta, reference_quirks)
+    x = np.stack([v_x, v_y, gamma], axis=-1).ravel()
+    return float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
