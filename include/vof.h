@@ -1,0 +1,123 @@
+/* vof.h - C ABI of the MI355X-native variational optical-flow solver (libvof.so).
+ *
+ * The reference has no FFI layer: its boundary is the Python function
+ *   source/optical_flow.py:715-724  variational_optical_flow(movie, delta_x, delta_t, speed_alpha,
+ *                                    remodelling_alpha, smoothing_sigma, initial_v_x, initial_v_y,
+ *                                    initial_remodelling, use_direct_solver)
+ * The entry points below are what a binding for that function calls (see INTEGRATION.md for the
+ * ctypes stub); each one names the reference lines it replaces.  Plain pointers and sizes only,
+ * no exceptions cross the ABI, no global state (contrast PETSc.Options(), OF.py:1081-1092).
+ *
+ * Conventions: images are row-major (N_i, N_j) float64, axis 0 = "x" = i, axis 1 = "y" = j
+ * (OF.py:730-733).  Pair k is (frame k, frame k+1) (OF.py:794-795).  Return value 0 = success,
+ * negative = error (message via vof_last_error).  Non-convergence is NOT an error: it is reported
+ * per pair in vof_pair_stats, like the reference which only prints a warning (OF.py:1135-1138).
+ */
+#ifndef VOF_H
+#define VOF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOF_VERSION 100 /* 0.1.0 */
+
+typedef struct vof_ctx vof_ctx;
+
+/* Solver parameters.  Defaults (vof_default_params) reproduce the reference's settings. */
+typedef struct vof_params {
+    double speed_alpha;        /* OF.py:718  */
+    double remodelling_alpha;  /* OF.py:719  */
+    double delta_x;            /* OF.py:716; velocities are returned in delta_x/delta_t units (OF.py:1189-1190) */
+    double delta_t;            /* OF.py:717  */
+    double initial_v_x;        /* OF.py:721,800: initial guess in delta_x/delta_t units */
+    double initial_v_y;        /* OF.py:722,801 */
+    double initial_remodelling;/* OF.py:723,802 */
+    double rtol;               /* OF.py:1120: 1e-6, ||b - A x||_2 <= rtol ||b||_2 (unpreconditioned, OF.py:1126) */
+    int32_t max_iterations;    /* OF.py:1120: 1000 BiCGStab iterations */
+    int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction (default 2) */
+    int32_t nu_post;           /* ... and after (default 2) */
+    int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
+    int32_t coarse_precision;  /* 0: float64 Galerkin stencils (default); 1: float32 storage */
+    int32_t reserved[3];
+} vof_params;
+
+/* Per-pair solver report (the reference prints these: OF.py:1131-1154). */
+typedef struct vof_pair_stats {
+    int32_t iterations;        /* BiCGStab iterations used */
+    int32_t converged;         /* 1 if the stopping rule was met (OF.py:1135 solver.is_converged) */
+    double relative_residual;  /* independent ||A x - b|| / ||b|| after the solve (OF.py:1151) */
+    double L1_functional;      /* OF.py:1178-1180 */
+    double speed_functional;   /* OF.py:1181-1182 (the true one; the dict-level bug is applied by the caller) */
+    double remodelling_functional; /* OF.py:1183 */
+} vof_pair_stats;
+
+/* Kernel classes for the built-in HIP-event profiler (vof_profile_*). */
+enum vof_kernel_id {
+    VOF_K_RHS = 0, VOF_K_APPLY0, VOF_K_GS0, VOF_K_GS, VOF_K_RESIDUAL, VOF_K_RESTRICT, VOF_K_PROLONG,
+    VOF_K_GALERKIN0, VOF_K_GALERKIN, VOF_K_COARSE_SETUP, VOF_K_COARSE_SOLVE, VOF_K_VECTOR, VOF_K_REDUCE,
+    VOF_K_FINALIZE, VOF_K_FUNCTIONALS, VOF_K_COUNT
+};
+
+int vof_version(void);
+void vof_default_params(vof_params* p);
+
+/* One context = one device = one host thread at a time.  Owns device workspaces for images of
+ * (n_i, n_j) and up to max_pairs_in_flight frame pairs solved concurrently (batch dimension).
+ * stream: a hipStream_t to launch on, or NULL for a context-owned stream. */
+int vof_create(vof_ctx** out, int device_id, int n_i, int n_j, int max_pairs_in_flight, void* stream);
+void vof_destroy(vof_ctx* ctx);
+const char* vof_last_error(const vof_ctx* ctx); /* ctx may be NULL: error of the last failed vof_create */
+size_t vof_workspace_bytes(const vof_ctx* ctx);
+/* Device bytes a context for (n_i, n_j, max_pairs_in_flight) allocates (without host-API staging). */
+size_t vof_query_workspace(int n_i, int n_j, int max_pairs_in_flight);
+/* Free / total device memory in bytes; returns 0 on success. */
+int vof_device_memory(int device_id, size_t* free_bytes, size_t* total_bytes);
+int vof_num_levels(const vof_ctx* ctx);
+
+/* Replaces the frame-pair loop OF.py:791-1186 + epilogue OF.py:1189-1191 for a whole stack.
+ * movie: (n_frames, n_i, n_j) float64 (already blurred if blurring is wanted, OF.py:770-773).
+ * v_x, v_y, remodelling, speed: (n_frames-1, n_i, n_j) float64, caller allocated; speed may be NULL.
+ * stats: n_frames-1 entries, host memory, may be NULL.
+ * _host: all array pointers are host memory (copies are staged by the library).
+ * _dev : all array pointers are device memory on the context's device (no PCIe traffic). */
+int vof_solve_stack_host(vof_ctx* ctx, const double* movie, int n_frames, const vof_params* p,
+                         double* v_x, double* v_y, double* remodelling, double* speed,
+                         vof_pair_stats* stats);
+int vof_solve_stack_dev(vof_ctx* ctx, const double* movie, int n_frames, const vof_params* p,
+                        double* v_x, double* v_y, double* remodelling, double* speed,
+                        vof_pair_stats* stats);
+
+/* Fixed-work kernel benchmark (SURVEY 8(d) "fixed sweep count"): n_sweeps full 4-colour block-GS
+ * sweeps of the fine level on n_pairs pairs of a device-resident movie.  Used by bench.py. */
+int vof_bench_sweeps_dev(vof_ctx* ctx, const double* movie, int n_pairs, const vof_params* p, int n_sweeps);
+
+/* Built-in profiler: when enabled, every kernel launch is bracketed by HIP events on the
+ * context's stream; totals are accumulated per kernel class and multigrid level. */
+int vof_profile_enable(vof_ctx* ctx, int on);
+int vof_profile_reset(vof_ctx* ctx);
+/* level < 0: sum over levels.  Outputs: number of launches, total milliseconds. */
+int vof_profile_get(vof_ctx* ctx, int kernel_id, int level, int64_t* launches, double* total_ms);
+const char* vof_kernel_name(int kernel_id);
+
+/* ---- debug / test entry points: single building blocks on device memory of the context -------
+ * All vectors are interior-grid vectors of level `level`, layout [pair][3][n_i(level)][n_j(level)].
+ * vof_debug_setup must be called first (uploads frames, builds the Galerkin hierarchy). */
+int vof_debug_setup(vof_ctx* ctx, const double* movie_host, int n_pairs, const vof_params* p);
+int vof_debug_level_shape(vof_ctx* ctx, int level, int* n_i, int* n_j);
+int vof_debug_rhs(vof_ctx* ctx, double* b_host);                                   /* level 0 */
+int vof_debug_apply(vof_ctx* ctx, int level, const double* x_host, double* y_host); /* y = A_l x */
+int vof_debug_gs(vof_ctx* ctx, int level, double* x_host, const double* b_host, int colour);
+int vof_debug_restrict(vof_ctx* ctx, int level, const double* fine_host, double* coarse_host);
+int vof_debug_prolong_add(vof_ctx* ctx, int level, double* fine_host, const double* coarse_host);
+int vof_debug_stencil(vof_ctx* ctx, int level, double* c_host); /* [pair][81][n_i][n_j], level >= 1 */
+int vof_debug_vcycle(vof_ctx* ctx, const double* r_host, double* e_host);
+int vof_debug_coarse_solve(vof_ctx* ctx, const double* r_host, double* e_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOF_H */

@@ -1,0 +1,791 @@
+// vof.hip - host side of libvof.so: context, workspace, multigrid hierarchy, BiCGStab driver, C ABI.
+//
+// Replaces the per-pair body of source/optical_flow.py::variational_optical_flow (OF.py:791-1186:
+// scipy.sparse assembly + PETSc KSP bcgs / composite PC) with a batched, matrix-free solve on one
+// MI355X: right-preconditioned BiCGStab (the reference's KSP type, OF.py:1081) whose preconditioner is
+// one geometric-multigrid V-cycle with a 4-colour 3x3-block Gauss-Seidel smoother and Galerkin coarse
+// operators; stopping rule ||b - A x|| <= rtol ||b|| (OF.py:1120,1126).  All frame pairs of a batch
+// advance together; per-pair scalars stay on the device.
+#include "vof_device.hpp"
+#include "../../include/vof.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace vof;
+
+namespace {
+
+constexpr int COARSEST_MAX = 9;      // coarsen until max(n_i, n_j) <= 9  (dense inverse of <= 243 unknowns)
+constexpr int MAX_PROF_RECS = 32768;
+
+struct Level {
+    int ni = 0, nj = 0;
+    size_t npts = 0;
+    void* C = nullptr;   // stored stencil [B][81][npts] (double or float); level 0: only for 1-level grids
+    double* x = nullptr; // levels >= 1
+    double* b = nullptr; // levels >= 1
+    double* r = nullptr; // residual scratch (all levels but the last)
+};
+
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int kid, level;
+};
+
+}  // namespace
+
+struct vof_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int Ni = 0, Nj = 0, B = 0;
+    std::vector<Level> L;
+    double *kx = nullptr, *kb = nullptr, *kr = nullptr, *krh = nullptr, *kp = nullptr, *kv = nullptr, *kt = nullptr,
+           *ky = nullptr;
+    double* partials = nullptr;
+    int nblk = 0;
+    PairScalars* sc = nullptr;
+    int* active = nullptr;
+    double* func3 = nullptr;
+    double *W = nullptr, *invT = nullptr;
+    int nd = 0;
+    // host mirrors (pinned)
+    int* h_active = nullptr;
+    PairScalars* h_sc = nullptr;
+    double* h_func3 = nullptr;
+    // staging for the host-pointer API (allocated lazily)
+    double* st_movie = nullptr;
+    double* st_out[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    std::string err;
+    // state of the last setup
+    const double* frames = nullptr;  // device pointer to frame 0 of the current batch
+    int npairs = 0;
+    vof_params prm;
+    bool hierarchy_float = false;
+    // profiler
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> free_events;
+    long long prof_dropped = 0;
+    double prof_ms[VOF_K_COUNT][16];
+    long long prof_n[VOF_K_COUNT][16];
+};
+
+static std::string g_create_error;
+
+namespace {
+
+struct Prof {
+    vof_ctx* c;
+    bool on;
+    ProfRec rec;
+    Prof(vof_ctx* c_, int kid, int level) : c(c_), on(false) {
+        if (!c->prof) return;
+        if ((int)c->recs.size() >= MAX_PROF_RECS) { c->prof_dropped++; return; }
+        if (c->free_events.size() >= 2) {
+            rec.e0 = c->free_events.back(); c->free_events.pop_back();
+            rec.e1 = c->free_events.back(); c->free_events.pop_back();
+        } else {
+            if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return;
+        }
+        rec.kid = kid; rec.level = level < 0 ? 0 : (level > 15 ? 15 : level);
+        on = true;
+        hipEventRecord(rec.e0, c->stream);
+    }
+    ~Prof() {
+        if (!on) return;
+        hipEventRecord(rec.e1, c->stream);
+        c->recs.push_back(rec);
+    }
+};
+
+void prof_collect(vof_ctx* c) {
+    if (c->recs.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            c->prof_ms[r.kid][r.level] += ms;
+            c->prof_n[r.kid][r.level] += 1;
+        }
+        c->free_events.push_back(r.e0);
+        c->free_events.push_back(r.e1);
+    }
+    c->recs.clear();
+}
+
+#define HIPCHK(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char buf_[512];                                                                        \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            c->err = buf_;                                                                         \
+            return -2;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+template <typename T>
+int dev_alloc(vof_ctx* c, T** p, size_t n) {
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 256);
+    HIPCHK(hipMalloc(&q, bytes));
+    c->allocs.push_back(q);
+    c->bytes += bytes;
+    *p = (T*)q;
+    return 0;
+}
+
+inline dim3 grid2d(int ni, int nj, int z) { return dim3((nj + BX - 1) / BX, (ni + BY - 1) / BY, z); }
+inline dim3 grid2d_colour(int ni, int nj, int colour, int z) {
+    int cp = colour >> 1, cq = colour & 1;
+    int mi = (ni - cp + 1) / 2, mj = (nj - cq + 1) / 2;
+    return dim3(std::max(1, (mj + BX - 1) / BX), std::max(1, (mi + BY - 1) / BY), z);
+}
+const dim3 blk2d(BX, BY, 1);
+
+inline size_t frame_stride(const vof_ctx* c) { return (size_t)c->Ni * c->Nj; }
+
+// ---------------------------------------------------------------- level kernels (dispatch on precision)
+void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np, const int* active) {
+    Level& lv = c->L[l];
+    dim3 g = grid2d_colour(lv.ni, lv.nj, colour, np);
+    if (l == 0 && c->L.size() > 1) {
+        Prof p(c, VOF_K_GS0, 0);
+        k_gs0<<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->prm.speed_alpha,
+                                          c->prm.remodelling_alpha, c->prm.reference_quirks, x, b, colour, active);
+    } else {
+        Prof p(c, VOF_K_GS, l);
+        if (c->hierarchy_float && l > 0)
+            k_gs<float><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, colour, active);
+        else
+            k_gs<double><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, colour, active);
+    }
+}
+
+// y = A_l x (mode 0) or y = b - A_l x (mode 1)
+void apply_level(vof_ctx* c, int l, const double* x, const double* b, double* y, int mode, int np,
+                 const int* active) {
+    Level& lv = c->L[l];
+    dim3 g = grid2d(lv.ni, lv.nj, np);
+    if (l == 0 && lv.C == nullptr) {
+        Prof p(c, VOF_K_APPLY0, 0);
+        if (mode)
+            k_apply0<1><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
+                                                    c->prm.speed_alpha, c->prm.remodelling_alpha,
+                                                    c->prm.reference_quirks, x, b, y, active);
+        else
+            k_apply0<0><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
+                                                    c->prm.speed_alpha, c->prm.remodelling_alpha,
+                                                    c->prm.reference_quirks, x, b, y, active);
+    } else {
+        Prof p(c, VOF_K_RESIDUAL, l);
+        bool f = c->hierarchy_float && l > 0;
+        if (f) {
+            if (mode) k_apply<float, 1><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
+            else k_apply<float, 0><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
+        } else {
+            if (mode) k_apply<double, 1><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
+            else k_apply<double, 0><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
+        }
+    }
+}
+
+void restrict_level(vof_ctx* c, int l, const double* fine, double* coarse, int np, const int* active) {
+    Level &f = c->L[l], &k = c->L[l + 1];
+    Prof p(c, VOF_K_RESTRICT, l);
+    k_restrict<<<grid2d(k.ni, k.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
+}
+
+void prolong_add_level(vof_ctx* c, int l, double* fine, const double* coarse, int np, const int* active) {
+    Level &f = c->L[l], &k = c->L[l + 1];
+    Prof p(c, VOF_K_PROLONG, l);
+    k_prolong_add<<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
+}
+
+void coarse_solve(vof_ctx* c, const double* r, double* e, int np, const int* active) {
+    Prof p(c, VOF_K_COARSE_SOLVE, (int)c->L.size() - 1);
+    k_coarse_solve<<<np, 256, c->nd * sizeof(double), c->stream>>>(c->invT, c->nd, r, e, active);
+}
+
+// One V-cycle: x (zero initial guess) ~= A^-1 b.
+void vcycle(vof_ctx* c, int l, double* x, const double* b, int np, const int* active) {
+    int last = (int)c->L.size() - 1;
+    if (l == last) { coarse_solve(c, b, x, np, active); return; }
+    Level& lv = c->L[l];
+    hipMemsetAsync(x, 0, (size_t)np * 3 * lv.npts * sizeof(double), c->stream);
+    for (int s = 0; s < c->prm.nu_pre; ++s)
+        for (int col = 0; col < 4; ++col) gs_colour(c, l, x, b, col, np, active);
+    apply_level(c, l, x, b, lv.r, 1, np, active);
+    Level& nx = c->L[l + 1];
+    restrict_level(c, l, lv.r, nx.b, np, active);
+    vcycle(c, l + 1, nx.x, nx.b, np, active);
+    prolong_add_level(c, l, x, nx.x, np, active);
+    for (int s = 0; s < c->prm.nu_post; ++s)
+        for (int col = 3; col >= 0; --col) gs_colour(c, l, x, b, col, np, active);
+}
+
+// Build the Galerkin hierarchy and the coarsest-level dense inverse for the current batch.
+int build_hierarchy(vof_ctx* c, int np) {
+    const vof_params& P = c->prm;
+    c->hierarchy_float = P.coarse_precision == 1;
+    int nl = (int)c->L.size();
+    for (int l = 0; l + 1 < nl; ++l) {
+        Level &f = c->L[l], &k = c->L[l + 1];
+        dim3 g = grid2d(k.ni, k.nj, np * 9);
+        if (l == 0) {
+            Prof p(c, VOF_K_GALERKIN0, 0);
+            if (c->hierarchy_float)
+                k_galerkin<double, float, true><<<g, blk2d, 0, c->stream>>>(
+                    c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
+                    nullptr, f.ni, f.nj, (float*)k.C, k.ni, k.nj);
+            else
+                k_galerkin<double, double, true><<<g, blk2d, 0, c->stream>>>(
+                    c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
+                    nullptr, f.ni, f.nj, (double*)k.C, k.ni, k.nj);
+        } else {
+            Prof p(c, VOF_K_GALERKIN, l);
+            if (c->hierarchy_float)
+                k_galerkin<float, float, false><<<g, blk2d, 0, c->stream>>>(
+                    nullptr, 0, 0, 0.0, 0.0, 0, (const float*)f.C, f.ni, f.nj, (float*)k.C, k.ni, k.nj);
+            else
+                k_galerkin<double, double, false><<<g, blk2d, 0, c->stream>>>(
+                    nullptr, 0, 0, 0.0, 0.0, 0, (const double*)f.C, f.ni, f.nj, (double*)k.C, k.ni, k.nj);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// The 1-level case needs the fine stencil in stored form.
+namespace vof {
+__global__ __launch_bounds__(NT) void k_store_fine_stencil(const double* __restrict__ frames, size_t frame_stride,
+                                                           int Nj, double alpha, double beta, int quirks, int ni,
+                                                           int nj, double* __restrict__ C) {
+    int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    if (p >= ni || q >= nj) return;
+    size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q;
+    PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
+    double* out = C + (size_t)pair * 81 * npts + idx;
+    for (int oi = -1; oi <= 1; ++oi)
+        for (int oj = -1; oj <= 1; ++oj) {
+            double blk[9];
+            int tp = p + oi, tq = q + oj;
+            if (tp < 0 || tp >= ni || tq < 0 || tq >= nj) {
+                for (int t = 0; t < 9; ++t) blk[t] = 0.0;
+            } else {
+                folded_block(k, alpha, beta, p, q, ni, nj, oi, oj, blk);
+            }
+            for (int t = 0; t < 9; ++t) out[(size_t)(((oi + 1) * 3 + (oj + 1)) * 9 + t) * npts] = blk[t];
+        }
+}
+}  // namespace vof
+
+namespace {
+
+int setup_batch(vof_ctx* c, const double* frames_dev, int np) {
+    c->frames = frames_dev;
+    c->npairs = np;
+    int nl = (int)c->L.size();
+    if (nl == 1) {
+        Level& f = c->L[0];
+        Prof p(c, VOF_K_GALERKIN0, 0);
+        k_store_fine_stencil<<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(
+            c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha,
+            c->prm.reference_quirks, f.ni, f.nj, (double*)f.C);
+        c->hierarchy_float = false;
+    } else {
+        build_hierarchy(c, np);
+    }
+    Level& last = c->L[nl - 1];
+    {
+        Prof p(c, VOF_K_COARSE_SETUP, nl - 1);
+        if (c->hierarchy_float && nl > 1)
+            k_coarse_build<float><<<np, 256, 0, c->stream>>>((const float*)last.C, last.ni, last.nj, c->W);
+        else
+            k_coarse_build<double><<<np, 256, 0, c->stream>>>((const double*)last.C, last.ni, last.nj, c->W);
+        k_coarse_invert<<<np, 1024, 0, c->stream>>>(c->W, c->nd, c->invT);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+inline dim3 rgrid(const vof_ctx* c, int np) { return dim3(c->nblk, np, 1); }
+
+int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double* vy, double* gm, double* speed,
+                vof_pair_stats* stats) {
+    const vof_params& P = c->prm;
+    if (int rc = setup_batch(c, frames_dev, np)) return rc;
+    Level& f = c->L[0];
+    const size_t len = 3 * f.npts;
+    hipStream_t s = c->stream;
+    // right-hand side and its norm
+    {
+        Prof p(c, VOF_K_RHS, 0);
+        k_rhs<<<grid2d(f.ni, f.nj, np), blk2d, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb);
+    }
+    { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kb, c->kb, nullptr, nullptr, len, c->partials, nullptr); }
+    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_BNORM><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+    // initial guess (OF.py:799-802: constants, in pixels/frame) and initial residual
+    double sx = P.delta_t / P.delta_x;
+    bool zero_guess = (P.initial_v_x == 0.0 && P.initial_v_y == 0.0 && P.initial_remodelling == 0.0);
+    if (zero_guess) {
+        HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)np * len * sizeof(double), s));
+        HIPCHK(hipMemcpyAsync(c->kr, c->kb, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
+    } else {
+        { Prof p(c, VOF_K_VECTOR, 0); k_fill<<<dim3(c->nblk, np), 256, 0, s>>>(c->kx, f.npts, P.initial_v_x * sx, P.initial_v_y * sx, P.initial_remodelling); }
+        apply_level(c, 0, c->kx, c->kb, c->kr, 1, np, nullptr);
+    }
+    HIPCHK(hipMemcpyAsync(c->krh, c->kr, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(c->kp, 0, (size_t)np * len * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(c->kv, 0, (size_t)np * len * sizeof(double), s));
+    { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kr, nullptr, nullptr, len, c->partials, nullptr); }
+    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R0><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+
+    for (int it = 0; it < P.max_iterations; ++it) {
+        HIPCHK(hipMemcpyAsync(c->h_active, c->active, np * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        int nact = 0;
+        for (int k = 0; k < np; ++k) nact += c->h_active[k] != 0;
+        if (nact == 0) break;
+        const int* act = c->active;
+        { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kr, nullptr, nullptr, len, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_RHO><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_update_p<<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act); }
+        vcycle(c, 0, c->ky, c->kp, np, act);                       // y = M p
+        apply_level(c, 0, c->ky, nullptr, c->kv, 0, np, act);      // v = A y
+        { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_update_s<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->ky, c->kr, c->kv, len, c->sc, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_S><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+        vcycle(c, 0, c->ky, c->kr, np, act);                       // z = M s
+        apply_level(c, 0, c->ky, nullptr, c->kt, 0, np, act);      // t = A z
+        { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_update_xr<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->ky, c->kr, c->kt, len, c->sc, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+    }
+    // independent residual (OF.py:1150-1151)
+    apply_level(c, 0, c->kx, c->kb, c->kt, 1, np, nullptr);
+    { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); }
+    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+    // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
+    { Prof p(c, VOF_K_FUNCTIONALS, 0);
+      k_functionals<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, P.speed_alpha,
+                                                  P.remodelling_alpha, P.reference_quirks, c->kx, c->partials);
+      k_sum3<<<np, 64, 0, s>>>(c->partials, c->nblk, c->func3); }
+    { Prof p(c, VOF_K_FINALIZE, 0);
+      k_finalize<<<grid2d(c->Ni, c->Nj, np), blk2d, 0, s>>>(c->kx, f.ni, f.nj, P.delta_x / P.delta_t, vx, vy, gm, speed); }
+    HIPCHK(hipGetLastError());
+    if (stats) {
+        HIPCHK(hipMemcpyAsync(c->h_sc, c->sc, np * sizeof(PairScalars), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c->h_func3, c->func3, np * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int k = 0; k < np; ++k) {
+            const PairScalars& q = c->h_sc[k];
+            stats[k].iterations = q.iterations;
+            stats[k].relative_residual = q.bnorm2 > 0 ? std::sqrt(q.rnorm2 / q.bnorm2) : 0.0;
+            stats[k].converged = (q.converged && !(stats[k].relative_residual > 10 * P.rtol)) ? 1 : 0;
+            stats[k].L1_functional = c->h_func3[3 * k];
+            stats[k].speed_functional = c->h_func3[3 * k + 1];
+            stats[k].remodelling_functional = c->h_func3[3 * k + 2];
+        }
+    }
+    return 0;
+}
+
+int check_params(vof_ctx* c, const vof_params* p) {
+    if (!p) { c->err = "params is NULL"; return -1; }
+    if (!(p->delta_x != 0.0) || !(p->delta_t != 0.0)) { c->err = "delta_x and delta_t must be non-zero"; return -1; }
+    if (p->nu_pre < 0 || p->nu_post < 0 || p->nu_pre + p->nu_post == 0) { c->err = "nu_pre + nu_post must be > 0"; return -1; }
+    if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
+    if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
+    c->prm = *p;
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================================ C ABI
+extern "C" {
+
+int vof_version(void) { return VOF_VERSION; }
+
+void vof_default_params(vof_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->speed_alpha = 1.0;          // OF.py:718
+    p->remodelling_alpha = 1000.0; // OF.py:719
+    p->delta_x = 1.0;
+    p->delta_t = 1.0;
+    p->rtol = 1e-6;                // OF.py:1120
+    p->max_iterations = 1000;      // OF.py:1120
+    p->nu_pre = 2;
+    p->nu_post = 2;
+    p->reference_quirks = 1;
+    p->coarse_precision = 0;
+}
+
+const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+size_t vof_workspace_bytes(const vof_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+int vof_num_levels(const vof_ctx* ctx) { return ctx ? (int)ctx->L.size() : 0; }
+
+size_t vof_query_workspace(int n_i, int n_j, int B) {
+    if (n_i < 4 || n_j < 4 || B < 1) return 0;
+    size_t ni = n_i - 2, nj = n_j - 2, total = 0, b = (size_t)B;
+    std::vector<std::pair<size_t, size_t>> lv{{ni, nj}};
+    while (std::max(lv.back().first, lv.back().second) > (size_t)COARSEST_MAX)
+        lv.push_back({(lv.back().first + 1) / 2, (lv.back().second + 1) / 2});
+    total += 8 * b * 3 * ni * nj;
+    for (size_t l = 0; l < lv.size(); ++l) {
+        size_t npts = lv[l].first * lv[l].second;
+        if (l + 1 < lv.size()) total += b * 3 * npts;
+        if (l > 0) total += 2 * b * 3 * npts;
+        if (l > 0 || lv.size() == 1) total += b * 81 * npts;
+    }
+    size_t nd = 3 * lv.back().first * lv.back().second;
+    total += b * nd * 2 * nd + b * nd * nd;
+    return total * sizeof(double) + (size_t)B * 3 * 256 * sizeof(double) + 4096;
+}
+
+int vof_device_memory(int device_id, size_t* free_bytes, size_t* total_bytes) {
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device_id) != hipSuccess) return -1;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) return -2;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
+const char* vof_kernel_name(int k) {
+    static const char* names[VOF_K_COUNT] = {"rhs", "apply0", "gs0", "gs", "residual", "restrict", "prolong",
+                                             "galerkin0", "galerkin", "coarse_setup", "coarse_solve", "vector",
+                                             "reduce", "finalize", "functionals"};
+    return (k >= 0 && k < VOF_K_COUNT) ? names[k] : "?";
+}
+
+void vof_destroy(vof_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->free_events) hipEventDestroy(e);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->h_active) hipHostFree(c->h_active);
+    if (c->h_sc) hipHostFree(c->h_sc);
+    if (c->h_func3) hipHostFree(c->h_func3);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void* stream) {
+    if (n_i < 4 || n_j < 4) { c->err = "image must be at least 4x4 (the mirror boundary rows need N >= 4)"; return -1; }
+    if (B < 1) { c->err = "max_pairs_in_flight must be >= 1"; return -1; }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) { c->err = "no such HIP device"; return -1; }
+    HIPCHK(hipSetDevice(device_id));
+    c->device = device_id;
+    c->Ni = n_i; c->Nj = n_j; c->B = B;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
+    memset(c->prof_ms, 0, sizeof c->prof_ms);
+    memset(c->prof_n, 0, sizeof c->prof_n);
+    vof_default_params(&c->prm);
+    // level shapes
+    Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
+    c->L.push_back(l0);
+    while (std::max(c->L.back().ni, c->L.back().nj) > COARSEST_MAX) {
+        Level k; k.ni = (c->L.back().ni + 1) / 2; k.nj = (c->L.back().nj + 1) / 2; k.npts = (size_t)k.ni * k.nj;
+        c->L.push_back(k);
+    }
+    int nl = (int)c->L.size();
+    if (nl > 16) { c->err = "too many levels"; return -1; }
+    size_t len0 = 3 * l0.npts;
+    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky})
+        if (int rc = dev_alloc(c, v, (size_t)B * len0)) return rc;
+    for (int l = 0; l < nl; ++l) {
+        Level& lv = c->L[l];
+        if (l + 1 < nl) if (int rc = dev_alloc(c, &lv.r, (size_t)B * 3 * lv.npts)) return rc;
+        if (l > 0) {
+            if (int rc = dev_alloc(c, &lv.x, (size_t)B * 3 * lv.npts)) return rc;
+            if (int rc = dev_alloc(c, &lv.b, (size_t)B * 3 * lv.npts)) return rc;
+        }
+        if (l > 0 || nl == 1) {
+            double* C = nullptr;
+            if (int rc = dev_alloc(c, &C, (size_t)B * 81 * lv.npts)) return rc;
+            lv.C = C;
+        }
+    }
+    c->nd = 3 * (int)c->L.back().npts;
+    if (int rc = dev_alloc(c, &c->W, (size_t)B * c->nd * 2 * c->nd)) return rc;
+    if (int rc = dev_alloc(c, &c->invT, (size_t)B * c->nd * c->nd)) return rc;
+    c->nblk = (int)std::min<size_t>(256, std::max<size_t>(1, (len0 + 4 * RBLK - 1) / (4 * RBLK)));
+    if (int rc = dev_alloc(c, &c->partials, (size_t)B * 3 * c->nblk)) return rc;
+    if (int rc = dev_alloc(c, &c->sc, (size_t)B)) return rc;
+    if (int rc = dev_alloc(c, &c->active, (size_t)B)) return rc;
+    if (int rc = dev_alloc(c, &c->func3, (size_t)B * 3)) return rc;
+    HIPCHK(hipHostMalloc((void**)&c->h_active, B * sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&c->h_sc, B * sizeof(PairScalars)));
+    HIPCHK(hipHostMalloc((void**)&c->h_func3, B * 3 * sizeof(double)));
+    return 0;
+}
+
+int vof_create(vof_ctx** out, int device_id, int n_i, int n_j, int max_pairs_in_flight, void* stream) {
+    if (!out) { g_create_error = "out is NULL"; return -1; }
+    *out = nullptr;
+    vof_ctx* c = new (std::nothrow) vof_ctx();
+    if (!c) { g_create_error = "out of host memory"; return -1; }
+    int rc = create_impl(c, device_id, n_i, n_j, max_pairs_in_flight, stream);
+    if (rc) {
+        g_create_error = c->err;
+        vof_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof_params* p, double* v_x, double* v_y,
+                        double* remodelling, double* speed, vof_pair_stats* stats) {
+    if (!c) return -1;
+    if (!movie || !v_x || !v_y || !remodelling) { c->err = "NULL array pointer"; return -1; }
+    if (n_frames < 2) { c->err = "need at least two frames"; return -1; }
+    if (int rc = check_params(c, p)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    size_t fs = frame_stride(c);
+    int P = n_frames - 1;
+    for (int k0 = 0; k0 < P; k0 += c->B) {
+        int np = std::min(c->B, P - k0);
+        int rc = solve_batch(c, movie + (size_t)k0 * fs, np, v_x + (size_t)k0 * fs, v_y + (size_t)k0 * fs,
+                             remodelling + (size_t)k0 * fs, speed ? speed + (size_t)k0 * fs : nullptr,
+                             stats ? stats + k0 : nullptr);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vof_params* p, double* v_x,
+                         double* v_y, double* remodelling, double* speed, vof_pair_stats* stats) {
+    if (!c) return -1;
+    if (!movie || !v_x || !v_y || !remodelling) { c->err = "NULL array pointer"; return -1; }
+    if (n_frames < 2) { c->err = "need at least two frames"; return -1; }
+    if (int rc = check_params(c, p)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    size_t fs = frame_stride(c);
+    if (!c->st_movie) {
+        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
+        for (int i = 0; i < 4; ++i)
+            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
+    }
+    int P = n_frames - 1;
+    for (int k0 = 0; k0 < P; k0 += c->B) {
+        int np = std::min(c->B, P - k0);
+        HIPCHK(hipMemcpyAsync(c->st_movie, movie + (size_t)k0 * fs, (size_t)(np + 1) * fs * sizeof(double),
+                              hipMemcpyHostToDevice, c->stream));
+        int rc = solve_batch(c, c->st_movie, np, c->st_out[0], c->st_out[1], c->st_out[2], c->st_out[3],
+                             stats ? stats + k0 : nullptr);
+        if (rc) return rc;
+        double* dst[4] = {v_x, v_y, remodelling, speed};
+        for (int i = 0; i < 4; ++i)
+            if (dst[i])
+                HIPCHK(hipMemcpyAsync(dst[i] + (size_t)k0 * fs, c->st_out[i], (size_t)np * fs * sizeof(double),
+                                      hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof_params* p, int n_sweeps) {
+    if (!c) return -1;
+    if (!movie) { c->err = "NULL movie"; return -1; }
+    if (n_pairs < 1 || n_pairs > c->B) { c->err = "n_pairs must be in [1, max_pairs_in_flight]"; return -1; }
+    if (c->L.size() < 2) { c->err = "grid too small for the sweep benchmark"; return -1; }
+    if (int rc = check_params(c, p)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    c->frames = movie;
+    c->npairs = n_pairs;
+    Level& f = c->L[0];
+    {
+        Prof pr(c, VOF_K_RHS, 0);
+        k_rhs<<<grid2d(f.ni, f.nj, n_pairs), blk2d, 0, c->stream>>>(movie, frame_stride(c), c->Nj, f.ni, f.nj, c->kb);
+    }
+    HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)n_pairs * 3 * f.npts * sizeof(double), c->stream));
+    for (int s = 0; s < n_sweeps; ++s)
+        for (int col = 0; col < 4; ++col) gs_colour(c, 0, c->kx, c->kb, col, n_pairs, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vof_profile_enable(vof_ctx* c, int on) {
+    if (!c) return -1;
+    if (!on) prof_collect(c);
+    c->prof = on != 0;
+    return 0;
+}
+
+int vof_profile_reset(vof_ctx* c) {
+    if (!c) return -1;
+    prof_collect(c);
+    memset(c->prof_ms, 0, sizeof c->prof_ms);
+    memset(c->prof_n, 0, sizeof c->prof_n);
+    c->prof_dropped = 0;
+    return 0;
+}
+
+int vof_profile_get(vof_ctx* c, int kid, int level, int64_t* launches, double* total_ms) {
+    if (!c) return -1;
+    if (kid < 0 || kid >= VOF_K_COUNT || level > 15) { c->err = "bad kernel id / level"; return -1; }
+    prof_collect(c);
+    long long n = 0; double ms = 0;
+    for (int l = 0; l < 16; ++l)
+        if (level < 0 || l == level) { n += c->prof_n[kid][l]; ms += c->prof_ms[kid][l]; }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- debug entry points
+static int dbg_ready(vof_ctx* c) {
+    if (!c) return -1;
+    if (!c->frames || c->npairs < 1) { c->err = "call vof_debug_setup first"; return -1; }
+    return 0;
+}
+
+int vof_debug_setup(vof_ctx* c, const double* movie_host, int n_pairs, const vof_params* p) {
+    if (!c) return -1;
+    if (!movie_host) { c->err = "NULL movie"; return -1; }
+    if (n_pairs < 1 || n_pairs > c->B) { c->err = "n_pairs must be in [1, max_pairs_in_flight]"; return -1; }
+    if (int rc = check_params(c, p)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    size_t fs = frame_stride(c);
+    if (!c->st_movie) {
+        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
+        for (int i = 0; i < 4; ++i)
+            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(c->st_movie, movie_host, (size_t)(n_pairs + 1) * fs * sizeof(double), hipMemcpyHostToDevice,
+                          c->stream));
+    if (int rc = setup_batch(c, c->st_movie, n_pairs)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vof_debug_level_shape(vof_ctx* c, int level, int* n_i, int* n_j) {
+    if (!c) return -1;
+    if (level < 0 || level >= (int)c->L.size()) { c->err = "bad level"; return -1; }
+    if (n_i) *n_i = c->L[level].ni;
+    if (n_j) *n_j = c->L[level].nj;
+    return 0;
+}
+
+#define DBG_LEVEL(level)                                                              \
+    if (int rc_ = dbg_ready(c)) return rc_;                                           \
+    if (level < 0 || level >= (int)c->L.size()) { c->err = "bad level"; return -1; } \
+    Level& lv = c->L[level];                                                          \
+    size_t nbytes = (size_t)c->npairs * 3 * lv.npts * sizeof(double);                 \
+    (void)nbytes;
+
+// scratch vectors for the debug API: reuse Krylov buffers (level-0 sized, always large enough)
+int vof_debug_rhs(vof_ctx* c, double* b_host) {
+    DBG_LEVEL(0)
+    k_rhs<<<grid2d(lv.ni, lv.nj, c->npairs), blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->kb);
+    HIPCHK(hipMemcpyAsync(b_host, c->kb, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vof_debug_apply(vof_ctx* c, int level, const double* x_host, double* y_host) {
+    DBG_LEVEL(level)
+    HIPCHK(hipMemcpyAsync(c->kp, x_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    apply_level(c, level, c->kp, nullptr, c->kv, 0, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(y_host, c->kv, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_debug_gs(vof_ctx* c, int level, double* x_host, const double* b_host, int colour) {
+    DBG_LEVEL(level)
+    if (colour < 0 || colour > 3) { c->err = "bad colour"; return -1; }
+    if (level == (int)c->L.size() - 1 && c->L.size() > 1 && false) { c->err = "coarsest level has no smoother"; return -1; }
+    HIPCHK(hipMemcpyAsync(c->kp, x_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->kv, b_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    gs_colour(c, level, c->kp, c->kv, colour, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(x_host, c->kp, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_debug_restrict(vof_ctx* c, int level, const double* fine_host, double* coarse_host) {
+    DBG_LEVEL(level)
+    if (level + 1 >= (int)c->L.size()) { c->err = "no coarser level"; return -1; }
+    Level& k = c->L[level + 1];
+    HIPCHK(hipMemcpyAsync(c->kp, fine_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    restrict_level(c, level, c->kp, c->kv, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(coarse_host, c->kv, (size_t)c->npairs * 3 * k.npts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_debug_prolong_add(vof_ctx* c, int level, double* fine_host, const double* coarse_host) {
+    DBG_LEVEL(level)
+    if (level + 1 >= (int)c->L.size()) { c->err = "no coarser level"; return -1; }
+    Level& k = c->L[level + 1];
+    HIPCHK(hipMemcpyAsync(c->kp, fine_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->kv, coarse_host, (size_t)c->npairs * 3 * k.npts * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    prolong_add_level(c, level, c->kp, c->kv, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(fine_host, c->kp, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
+    DBG_LEVEL(level)
+    if (!lv.C) { c->err = "level has no stored stencil"; return -1; }
+    size_t n = (size_t)c->npairs * 81 * lv.npts;
+    if (c->hierarchy_float && level > 0) {
+        std::vector<float> tmp(n);
+        HIPCHK(hipMemcpy(tmp.data(), lv.C, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) c_host[i] = tmp[i];
+    } else {
+        HIPCHK(hipMemcpy(c_host, lv.C, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int vof_debug_vcycle(vof_ctx* c, const double* r_host, double* e_host) {
+    DBG_LEVEL(0)
+    HIPCHK(hipMemcpyAsync(c->kp, r_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    vcycle(c, 0, c->ky, c->kp, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(e_host, c->ky, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_debug_coarse_solve(vof_ctx* c, const double* r_host, double* e_host) {
+    int last = c ? (int)c->L.size() - 1 : 0;
+    DBG_LEVEL(last)
+    HIPCHK(hipMemcpyAsync(c->kp, r_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    coarse_solve(c, c->kp, c->kv, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(e_host, c->kv, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

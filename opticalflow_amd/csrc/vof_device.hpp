@@ -1,0 +1,787 @@
+// vof_device.hpp - device code (gfx950) of the variational optical-flow solver.
+//
+// All kernels are bandwidth-bound FP64 stencil / vector kernels (no MFMA: arithmetic intensity of
+// the block-GS sweep is ~2 flop/B, far below the FP64 ridge).  Layout: SoA planes, axis 1 ("y", j)
+// contiguous and mapped to the lanes of a wave so every global access is a coalesced row segment;
+// blockIdx.z (or .y for 1-D kernels) is the frame pair, so one launch covers the whole batch.
+//
+// The linear system is the reference's (source/optical_flow.py:833-1072) with the boundary unknowns
+// eliminated: unknowns live on the interior grid n = N - 2; a ghost neighbour folds onto an interior
+// point (edge ghost -> its mirror point, corner ghost -> 2 x the diagonal mirror point) which is
+// exactly what the boundary rows OF.py:964-1070 (with their overlapping corner entries) impose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vof {
+
+constexpr int BX = 64;  // lanes along j
+constexpr int BY = 4;   // rows per block
+constexpr int NT = BX * BY;
+
+struct PairScalars {
+    double rho, alpha, omega, beta;
+    double bnorm2, rnorm2;
+    double tol2;      // rtol^2 * bnorm2
+    int iterations;
+    int converged;
+    int breakdown;
+    int pad;
+};
+
+__device__ __forceinline__ int fold(int t, int n) { return t < 0 ? 1 : (t >= n ? n - 2 : t); }
+
+// weight of fine point f in the prolongation column of coarse point c (1-D), nc = #coarse points.
+__device__ __forceinline__ double pweight(int f, int c, int nc) {
+    int d = f - 2 * c;
+    if (d == 0) return 1.0;
+    if (d == -1) return 0.5;
+    if (d == 1) return (c + 1 < nc) ? 0.5 : 1.0;  // orphan last odd point copies its left neighbour
+    return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Image-derived coefficients of one interior pixel (OF.py:812-827).
+// ------------------------------------------------------------------------------------------
+struct PixCoef {
+    double P, Dx, Dy, Dxx, Dyy, Dxy;
+};
+
+// I points at the pair's previous frame (full grid, pitch Nj); (p, q) are interior indices.
+__device__ __forceinline__ PixCoef pix_coef(const double* __restrict__ I, int Nj, int p, int q, int quirks) {
+    const double* c = I + (size_t)(p + 1) * Nj + (q + 1);
+    double i00 = c[0];
+    double im0 = c[-Nj], ip0 = c[Nj], i0m = c[-1], i0p = c[1];
+    double imm = c[-Nj - 1], imp = c[-Nj + 1], ipm = c[Nj - 1], ipp = c[Nj + 1];
+    PixCoef k;
+    k.P = i00;
+    k.Dx = (ip0 - im0) / 2;                        // OF.py:696-697
+    k.Dy = quirks ? k.Dx : (i0p - i0m) / 2;        // OF.py:698-699 ('dy' returns the x-derivative)
+    k.Dxx = ip0 + im0 - 2 * i00;                   // OF.py:702-703
+    k.Dyy = i0p + i0m - 2 * i00;                   // OF.py:704-705
+    k.Dxy = (ipp - ipm - imp + imm) / 4;           // OF.py:700-701
+    return k;
+}
+
+// blk[r*3+c] += scale * (raw 3x3 block of offset (oi, oj)), OF.py:843-960.
+__device__ __forceinline__ void add_raw_block(const PixCoef& k, double alpha, double beta, int oi, int oj,
+                                              double scale, double* blk) {
+    const double P = k.P;
+    if (oi == 0 && oj == 0) {
+        blk[0] += scale * (P * (k.Dxx + -2 * P) - 4 * alpha);
+        blk[1] += scale * (P * k.Dxy);
+        blk[3] += scale * (P * k.Dxy);
+        blk[4] += scale * (P * (k.Dyy + -2 * P) - 4 * alpha);
+        blk[6] += scale * k.Dx;
+        blk[7] += scale * k.Dy;
+        blk[8] += scale * (-1 - 4 * beta);
+    } else if (oj == 0) {  // (+-1, 0)
+        double s = (double)oi;
+        blk[0] += scale * (P * (s * k.Dx + P) + alpha);
+        blk[1] += scale * (s * P * k.Dy / 2);
+        blk[2] += scale * (-s * P / 2);
+        blk[3] += scale * (s * P * k.Dy / 2);
+        blk[4] += scale * alpha;
+        blk[6] += scale * (s * P / 2);
+        blk[8] += scale * beta;
+    } else if (oi == 0) {  // (0, +-1)
+        double s = (double)oj;
+        blk[0] += scale * alpha;
+        blk[1] += scale * (s * P * k.Dx / 2);
+        blk[3] += scale * (s * P * k.Dx / 2);
+        blk[4] += scale * (P * (s * k.Dy + P) + alpha);
+        blk[5] += scale * (-s * P / 2);
+        blk[7] += scale * (s * P / 2);
+        blk[8] += scale * beta;
+    } else {  // diagonals: +P^2/4 for (-1,-1),(+1,+1); -P^2/4 for the other two
+        double s = (double)(oi * oj);
+        blk[1] += scale * (s * P * P / 4);
+        blk[3] += scale * (s * P * P / 4);
+    }
+}
+
+// Folded block of offset (oi, oj) at interior point (p, q): the ghost couplings are added onto the
+// interior point they mirror to.  The target (p+oi, q+oj) must be inside the grid.
+__device__ __forceinline__ void folded_block(const PixCoef& k, double alpha, double beta, int p, int q, int ni,
+                                             int nj, int oi, int oj, double* blk) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) blk[t] = 0.0;
+    bool gi = (oi == 1 && p == 0) || (oi == -1 && p == ni - 1);  // ghost -oi folds onto +oi
+    bool gj = (oj == 1 && q == 0) || (oj == -1 && q == nj - 1);
+    add_raw_block(k, alpha, beta, oi, oj, 1.0, blk);
+    if (gi) add_raw_block(k, alpha, beta, -oi, oj, 1.0, blk);
+    if (gj) add_raw_block(k, alpha, beta, oi, -oj, 1.0, blk);
+    if (gi && gj) add_raw_block(k, alpha, beta, -oi, -oj, 2.0, blk);  // corner ghost = 2 x(2,2)
+}
+
+// ------------------------------------------------------------------------------------------
+// Level-0 (matrix-free) neighbourhood of the unknowns with folded ghosts.
+// ------------------------------------------------------------------------------------------
+struct Nbr {
+    double u[9], w[9], g[9];  // index (di+1)*3 + (dj+1); g only at the 5-point positions
+};
+
+__device__ __forceinline__ void load_nbr(const double* __restrict__ x, size_t npts, int ni, int nj, int p, int q,
+                                         Nbr& n) {
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+        int tp = p + di;
+        bool oi = (tp < 0) || (tp >= ni);
+        int fp = fold(tp, ni);
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            int tq = q + dj;
+            bool oj = (tq < 0) || (tq >= nj);
+            int fq = fold(tq, nj);
+            size_t idx = (size_t)fp * nj + fq;
+            double s = (oi && oj) ? 2.0 : 1.0;
+            int t = (di + 1) * 3 + (dj + 1);
+            n.u[t] = s * x[idx];
+            n.w[t] = s * x[npts + idx];
+            if (di == 0 || dj == 0) n.g[t] = s * x[2 * npts + idx];
+        }
+    }
+}
+
+// Off-diagonal part of A x at a point (everything except the 3x3 diagonal block) and the full product.
+// Index helpers: mm=0 m0=1 mp=2 0m=3 00=4 0p=5 pm=6 p0=7 pp=8.
+__device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double beta, const Nbr& n, double& y0,
+                                         double& y1, double& y2) {
+    const double P = k.P;
+    const double hPDx = P * k.Dx / 2, hPDy = P * k.Dy / 2, qPP = P * P / 4, hP = P / 2;
+    y0 = (P * (P - k.Dx) + alpha) * n.u[1] + (P * (P + k.Dx) + alpha) * n.u[7] + alpha * (n.u[3] + n.u[5]) +
+         hPDx * (n.w[5] - n.w[3]) + hPDy * (n.w[7] - n.w[1]) + qPP * (n.w[0] + n.w[8] - n.w[2] - n.w[6]) +
+         hP * (n.g[1] - n.g[7]);
+    y1 = (P * (P - k.Dy) + alpha) * n.w[3] + (P * (P + k.Dy) + alpha) * n.w[5] + alpha * (n.w[1] + n.w[7]) +
+         hPDy * (n.u[7] - n.u[1]) + hPDx * (n.u[5] - n.u[3]) + qPP * (n.u[0] + n.u[8] - n.u[2] - n.u[6]) +
+         hP * (n.g[3] - n.g[5]);
+    y2 = beta * (n.g[1] + n.g[7] + n.g[3] + n.g[5]) + hP * (n.u[7] - n.u[1]) + hP * (n.w[5] - n.w[3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rhs: b = (-P Dxt, -P Dyt, -Dt) on the interior (OF.py:889,938,962).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_rhs(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
+                                            int nj, double* __restrict__ b) {
+    int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    if (p >= ni || q >= nj) return;
+    const double* I = frames + (size_t)pair * frame_stride + (size_t)(p + 1) * Nj + (q + 1);
+    const double* J = I + frame_stride;
+    double P = I[0];
+    double dxt = (J[Nj] - J[-Nj] - I[Nj] + I[-Nj]) / 2;  // OF.py:815-816
+    double dyt = (J[1] - J[-1] - I[1] + I[-1]) / 2;      // OF.py:818-819
+    double dt = J[0] - I[0];                              // OF.py:821-823
+    size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q;
+    double* bp = b + (size_t)pair * 3 * npts;
+    bp[idx] = -P * dxt;
+    bp[npts + idx] = -P * dyt;
+    bp[2 * npts + idx] = -dt;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_apply0: y = A x (MODE 0) or y = b - A x (MODE 1) on the fine level, matrix-free.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(NT) void k_apply0(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
+                                               int nj, double alpha, double beta, int quirks,
+                                               const double* __restrict__ x, const double* __restrict__ b,
+                                               double* __restrict__ y, const int* __restrict__ active) {
+    int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    if (p >= ni || q >= nj) return;
+    size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
+    PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
+    Nbr n;
+    load_nbr(x + off, npts, ni, nj, p, q, n);
+    double y0, y1, y2;
+    offdiag0(k, alpha, beta, n, y0, y1, y2);
+    const double P = k.P;
+    y0 += (P * (k.Dxx - 2 * P) - 4 * alpha) * n.u[4] + P * k.Dxy * n.w[4];
+    y1 += (P * (k.Dyy - 2 * P) - 4 * alpha) * n.w[4] + P * k.Dxy * n.u[4];
+    y2 += (-1 - 4 * beta) * n.g[4] + k.Dx * n.u[4] + k.Dy * n.w[4];
+    if (MODE == 1) {
+        y0 = b[off + idx] - y0;
+        y1 = b[off + npts + idx] - y1;
+        y2 = b[off + 2 * npts + idx] - y2;
+    }
+    y[off + idx] = y0;
+    y[off + npts + idx] = y1;
+    y[off + 2 * npts + idx] = y2;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gs0: one colour of the 4-colour 3x3-block Gauss-Seidel sweep on the fine level (in place).
+// colour = 2 (p mod 2) + (q mod 2).  The diagonal block is lower-triangular in gamma:
+//   [[axx, c, 0], [c, ayy, 0], [Dx, Dy, -1-4 beta]]  ->  2x2 solve, then back-substitution.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_gs0(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
+                                            int nj, double alpha, double beta, int quirks, double* __restrict__ x,
+                                            const double* __restrict__ b, int colour,
+                                            const int* __restrict__ active) {
+    int pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    int q = 2 * (blockIdx.x * BX + threadIdx.x) + (colour & 1);
+    int p = 2 * (blockIdx.y * BY + threadIdx.y) + (colour >> 1);
+    if (p >= ni || q >= nj) return;
+    size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
+    PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
+    Nbr n;
+    load_nbr(x + off, npts, ni, nj, p, q, n);
+    double y0, y1, y2;
+    offdiag0(k, alpha, beta, n, y0, y1, y2);
+    const double P = k.P;
+    double r0 = b[off + idx] - y0, r1 = b[off + npts + idx] - y1, r2 = b[off + 2 * npts + idx] - y2;
+    double axx = P * (k.Dxx - 2 * P) - 4 * alpha, ayy = P * (k.Dyy - 2 * P) - 4 * alpha, c = P * k.Dxy;
+    double inv = 1.0 / (axx * ayy - c * c);
+    double u = (r0 * ayy - c * r1) * inv;
+    double w = (axx * r1 - c * r0) * inv;
+    double g = (r2 - k.Dx * u - k.Dy * w) / (-1 - 4 * beta);
+    x[off + idx] = u;
+    x[off + npts + idx] = w;
+    x[off + 2 * npts + idx] = g;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stored-stencil levels (Galerkin coarse operators): C[pair][(a*3+b)*9 + r*3+c][npts].
+// ------------------------------------------------------------------------------------------
+template <typename CT>
+__device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t npts, const double* __restrict__ x,
+                                                int ni, int nj, int p, int q, double& y0, double& y1, double& y2,
+                                                bool include_diag) {
+    size_t idx = (size_t)p * nj + q;
+    y0 = y1 = y2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int tp = p + a - 1;
+        if (tp < 0 || tp >= ni) continue;
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            int tq = q + bb - 1;
+            if (tq < 0 || tq >= nj) continue;
+            if (!include_diag && a == 1 && bb == 1) continue;
+            size_t t = (size_t)tp * nj + tq;
+            double xu = x[t], xw = x[npts + t], xg = x[2 * npts + t];
+            const CT* cb = C + (size_t)((a * 3 + bb) * 9) * npts + idx;
+            y0 += (double)cb[0] * xu + (double)cb[npts] * xw + (double)cb[2 * npts] * xg;
+            y1 += (double)cb[3 * npts] * xu + (double)cb[4 * npts] * xw + (double)cb[5 * npts] * xg;
+            y2 += (double)cb[6 * npts] * xu + (double)cb[7 * npts] * xw + (double)cb[8 * npts] * xg;
+        }
+    }
+}
+
+template <typename CT, int MODE>
+__global__ __launch_bounds__(NT) void k_apply(const CT* __restrict__ C, int ni, int nj, const double* __restrict__ x,
+                                              const double* __restrict__ b, double* __restrict__ y,
+                                              const int* __restrict__ active) {
+    int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    if (p >= ni || q >= nj) return;
+    size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
+    double y0, y1, y2;
+    stencil_offdiag<CT>(C + (size_t)pair * 81 * npts, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
+    if (MODE == 1) {
+        y0 = b[off + idx] - y0;
+        y1 = b[off + npts + idx] - y1;
+        y2 = b[off + 2 * npts + idx] - y2;
+    }
+    y[off + idx] = y0;
+    y[off + npts + idx] = y1;
+    y[off + 2 * npts + idx] = y2;
+}
+
+__device__ __forceinline__ void solve3(const double* D, double r0, double r1, double r2, double& x0, double& x1,
+                                       double& x2) {
+    double a = D[0], b = D[1], c = D[2], d = D[3], e = D[4], f = D[5], g = D[6], h = D[7], i = D[8];
+    double co00 = e * i - f * h, co01 = -(d * i - f * g), co02 = d * h - e * g;
+    double inv = 1.0 / (a * co00 + b * co01 + c * co02);
+    x0 = (r0 * co00 + r1 * -(b * i - c * h) + r2 * (b * f - c * e)) * inv;
+    x1 = (r0 * co01 + r1 * (a * i - c * g) + r2 * -(a * f - c * d)) * inv;
+    x2 = (r0 * co02 + r1 * -(a * h - b * g) + r2 * (a * e - b * d)) * inv;
+}
+
+template <typename CT>
+__global__ __launch_bounds__(NT) void k_gs(const CT* __restrict__ C, int ni, int nj, double* __restrict__ x,
+                                           const double* __restrict__ b, int colour,
+                                           const int* __restrict__ active) {
+    int pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    int q = 2 * (blockIdx.x * BX + threadIdx.x) + (colour & 1);
+    int p = 2 * (blockIdx.y * BY + threadIdx.y) + (colour >> 1);
+    if (p >= ni || q >= nj) return;
+    size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
+    const CT* Cp = C + (size_t)pair * 81 * npts;
+    double y0, y1, y2;
+    stencil_offdiag<CT>(Cp, npts, x + off, ni, nj, p, q, y0, y1, y2, false);
+    double D[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) D[t] = (double)Cp[(size_t)(36 + t) * npts + idx];
+    double x0, x1, x2;
+    solve3(D, b[off + idx] - y0, b[off + npts + idx] - y1, b[off + 2 * npts + idx] - y2, x0, x1, x2);
+    x[off + idx] = x0;
+    x[off + npts + idx] = x1;
+    x[off + 2 * npts + idx] = x2;
+}
+
+// ------------------------------------------------------------------------------------------
+// Transfer operators.  Coarse point c sits on fine point 2c; R = P^T / 4.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_restrict(const double* __restrict__ fine, int nfi, int nfj,
+                                                 double* __restrict__ coarse, int nci, int ncj,
+                                                 const int* __restrict__ active) {
+    int cq = blockIdx.x * BX + threadIdx.x, cp = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    if (cp >= nci || cq >= ncj) return;
+    size_t nf = (size_t)nfi * nfj, nc = (size_t)nci * ncj;
+    const double* f = fine + (size_t)pair * 3 * nf;
+    double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+        int fp = 2 * cp + di;
+        if (fp < 0 || fp >= nfi) continue;
+        double wi = pweight(fp, cp, nci);
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            int fq = 2 * cq + dj;
+            if (fq < 0 || fq >= nfj) continue;
+            double w = wi * pweight(fq, cq, ncj);
+            size_t t = (size_t)fp * nfj + fq;
+            s0 += w * f[t];
+            s1 += w * f[nf + t];
+            s2 += w * f[2 * nf + t];
+        }
+    }
+    size_t idx = (size_t)cp * ncj + cq;
+    double* c = coarse + (size_t)pair * 3 * nc;
+    c[idx] = 0.25 * s0;
+    c[nc + idx] = 0.25 * s1;
+    c[2 * nc + idx] = 0.25 * s2;
+}
+
+__global__ __launch_bounds__(NT) void k_prolong_add(double* __restrict__ fine, int nfi, int nfj,
+                                                    const double* __restrict__ coarse, int nci, int ncj,
+                                                    const int* __restrict__ active) {
+    int fq = blockIdx.x * BX + threadIdx.x, fp = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    if (fp >= nfi || fq >= nfj) return;
+    size_t nf = (size_t)nfi * nfj, nc = (size_t)nci * ncj;
+    const double* c = coarse + (size_t)pair * 3 * nc;
+    int cp0 = fp >> 1, cq0 = fq >> 1;
+    double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        int cp = cp0 + a;
+        if (cp >= nci) continue;
+        double wi = pweight(fp, cp, nci);
+        if (wi == 0.0) continue;
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            int cq = cq0 + bb;
+            if (cq >= ncj) continue;
+            double w = wi * pweight(fq, cq, ncj);
+            if (w == 0.0) continue;
+            size_t t = (size_t)cp * ncj + cq;
+            s0 += w * c[t];
+            s1 += w * c[nc + t];
+            s2 += w * c[2 * nc + t];
+        }
+    }
+    size_t idx = (size_t)fp * nfj + fq;
+    double* f = fine + (size_t)pair * 3 * nf;
+    f[idx] += s0;
+    f[nf + idx] += s1;
+    f[2 * nf + idx] += s2;
+}
+
+// ------------------------------------------------------------------------------------------
+// Galerkin coarse operator A_c = R A P, one thread per (coarse point C, coarse neighbour D = C + (a,b)):
+//   A_c(C, D) = 1/4 sum_f sum_g w(f, C) A(f, g) w(g, D),  f in 2C + {-1,0,1}^2, g in f + {-1,0,1}^2.
+// LEVEL0: A(f, g) is computed on the fly from the image; otherwise it is read from the stored stencil.
+// ------------------------------------------------------------------------------------------
+template <typename CTF, typename CTC, bool LEVEL0>
+__global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ frames, size_t frame_stride, int Nj,
+                                                 double alpha, double beta, int quirks,
+                                                 const CTF* __restrict__ Cf, int nfi, int nfj,
+                                                 CTC* __restrict__ Cc, int nci, int ncj) {
+    int cq = blockIdx.x * BX + threadIdx.x, cp = blockIdx.y * BY + threadIdx.y;
+    int pair = blockIdx.z / 9, off = blockIdx.z % 9;
+    if (cp >= nci || cq >= ncj) return;
+    int a = off / 3 - 1, b = off % 3 - 1;
+    int Dp = cp + a, Dq = cq + b;
+    size_t nf = (size_t)nfi * nfj, nc = (size_t)nci * ncj;
+    double acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.0;
+    if (Dp >= 0 && Dp < nci && Dq >= 0 && Dq < ncj) {
+        for (int fi = -1; fi <= 1; ++fi) {
+            int fp = 2 * cp + fi;
+            if (fp < 0 || fp >= nfi) continue;
+            double wfi = pweight(fp, cp, nci);
+            for (int fj = -1; fj <= 1; ++fj) {
+                int fq = 2 * cq + fj;
+                if (fq < 0 || fq >= nfj) continue;
+                double wf = wfi * pweight(fq, cq, ncj);
+                PixCoef k;
+                if (LEVEL0) k = pix_coef(frames + (size_t)pair * frame_stride, Nj, fp, fq, quirks);
+                for (int oi = -1; oi <= 1; ++oi) {
+                    int gp = fp + oi;
+                    if (gp < 0 || gp >= nfi) continue;
+                    double wgi = pweight(gp, Dp, nci);
+                    if (wgi == 0.0) continue;
+                    for (int oj = -1; oj <= 1; ++oj) {
+                        int gq = fq + oj;
+                        if (gq < 0 || gq >= nfj) continue;
+                        double w = wf * wgi * pweight(gq, Dq, ncj);
+                        if (w == 0.0) continue;
+                        if (LEVEL0) {
+                            double blk[9];
+                            folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk);
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) acc[t] += w * blk[t];
+                        } else {
+                            const CTF* cb = Cf + (size_t)pair * 81 * nf + (size_t)(((oi + 1) * 3 + (oj + 1)) * 9) * nf +
+                                            (size_t)fp * nfj + fq;
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) acc[t] += w * (double)cb[(size_t)t * nf];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    CTC* out = Cc + (size_t)pair * 81 * nc + (size_t)(off * 9) * nc + (size_t)cp * ncj + cq;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) out[(size_t)t * nc] = (CTC)(0.25 * acc[t]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Coarsest level: dense inverse by Gauss-Jordan with partial pivoting (one block per pair, once per
+// stack), applied as a mat-vec in every V-cycle.  W is [nd][2 nd] row-major in global memory (L2).
+// ------------------------------------------------------------------------------------------
+template <typename CT>
+__global__ void k_coarse_build(const CT* __restrict__ C, int ni, int nj, double* __restrict__ W) {
+    int pair = blockIdx.x;
+    int npts = ni * nj, nd = 3 * npts;
+    double* Wp = W + (size_t)pair * nd * 2 * nd;
+    for (int t = threadIdx.x; t < nd * 2 * nd; t += blockDim.x) {
+        int row = t / (2 * nd), col = t % (2 * nd);
+        Wp[t] = (col == nd + row) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const CT* Cp = C + (size_t)pair * 81 * npts;
+    for (int t = threadIdx.x; t < 81 * npts; t += blockDim.x) {
+        int plane = t / npts, pt = t % npts;
+        int ab = plane / 9, rc = plane % 9;
+        int a = ab / 3 - 1, b = ab % 3 - 1, r = rc / 3, c = rc % 3;
+        int p = pt / nj, q = pt % nj, tp = p + a, tq = q + b;
+        if (tp < 0 || tp >= ni || tq < 0 || tq >= nj) continue;
+        Wp[(size_t)(r * npts + pt) * 2 * nd + (c * npts + tp * nj + tq)] = (double)Cp[t];
+    }
+}
+
+__global__ void k_coarse_invert(double* __restrict__ W, int nd, double* __restrict__ invT) {
+    int pair = blockIdx.x;
+    double* Wp = W + (size_t)pair * nd * 2 * nd;
+    const int ld = 2 * nd;
+    __shared__ double s_val[1024];
+    __shared__ int s_idx[1024];
+    __shared__ int s_piv;
+    for (int k = 0; k < nd; ++k) {
+        // pivot search in column k, rows >= k
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + threadIdx.x; i < nd; i += blockDim.x) {
+            double v = fabs(Wp[(size_t)i * ld + k]);
+            if (v > best) { best = v; bi = i; }
+        }
+        s_val[threadIdx.x] = best;
+        s_idx[threadIdx.x] = bi;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                double v2 = s_val[threadIdx.x + s];
+                int i2 = s_idx[threadIdx.x + s];
+                if (v2 > s_val[threadIdx.x] || (v2 == s_val[threadIdx.x] && i2 < s_idx[threadIdx.x])) {
+                    s_val[threadIdx.x] = v2;
+                    s_idx[threadIdx.x] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) s_piv = s_idx[0];
+        __syncthreads();
+        int piv = s_piv;
+        if (piv != k) {
+            for (int j = k + threadIdx.x; j < ld; j += blockDim.x) {
+                double t1 = Wp[(size_t)k * ld + j], t2 = Wp[(size_t)piv * ld + j];
+                Wp[(size_t)k * ld + j] = t2;
+                Wp[(size_t)piv * ld + j] = t1;
+            }
+        }
+        __syncthreads();
+        double pinv = 1.0 / Wp[(size_t)k * ld + k];
+        // eliminate column k from every other row over columns k+1 .. 2nd-1 (row swaps permute the
+        // identity half, so no column range of it can be skipped); column k itself is never written,
+        // so the multipliers stay valid during the step.
+        int ncol = ld - k - 1;
+        for (int t = threadIdx.x; t < nd * ncol; t += blockDim.x) {
+            int i = t / ncol, j = k + 1 + t % ncol;
+            if (i == k) continue;
+            double m = Wp[(size_t)i * ld + k] * pinv;
+            Wp[(size_t)i * ld + j] -= m * Wp[(size_t)k * ld + j];
+        }
+        __syncthreads();
+        for (int j = k + 1 + threadIdx.x; j < ld; j += blockDim.x) Wp[(size_t)k * ld + j] *= pinv;
+        __syncthreads();
+    }
+    double* out = invT + (size_t)pair * nd * nd;
+    for (int t = threadIdx.x; t < nd * nd; t += blockDim.x) {
+        int j = t / nd, i = t % nd;  // invT[j][i] = inv[i][j]
+        out[t] = Wp[(size_t)i * ld + nd + j];
+    }
+}
+
+__global__ void k_coarse_solve(const double* __restrict__ invT, int nd, const double* __restrict__ r,
+                               double* __restrict__ e, const int* __restrict__ active) {
+    int pair = blockIdx.x;
+    if (active && !active[pair]) return;
+    extern __shared__ double s_r[];
+    for (int j = threadIdx.x; j < nd; j += blockDim.x) s_r[j] = r[(size_t)pair * nd + j];
+    __syncthreads();
+    const double* M = invT + (size_t)pair * nd * nd;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        double s = 0.0;
+        for (int j = 0; j < nd; ++j) s += M[(size_t)j * nd + i] * s_r[j];
+        e[(size_t)pair * nd + i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Vector kernels of BiCGStab.  Per-pair scalars live on the device (no host sync inside an iteration);
+// reductions are two-stage and deterministic: per-block partials, summed in fixed order by k_scalar.
+// ------------------------------------------------------------------------------------------
+constexpr int RBLK = 256;  // threads per reduction block
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_store_partials(double v0, double v1, double v2, double* __restrict__ partials,
+                                                     int nslots_used, int nblk, int pair, int blk) {
+    __shared__ double s[3][RBLK / 64];
+    v0 = wave_sum(v0);
+    if (nslots_used > 1) v1 = wave_sum(v1);
+    if (nslots_used > 2) v2 = wave_sum(v2);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s[0][wv] = v0; s[1][wv] = v1; s[2][wv] = v2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int i = 0; i < RBLK / 64; ++i) { t0 += s[0][i]; t1 += s[1][i]; t2 += s[2][i]; }
+        double* pp = partials + ((size_t)pair * 3) * nblk + blk;
+        pp[0] = t0;
+        if (nslots_used > 1) pp[nblk] = t1;
+        if (nslots_used > 2) pp[2 * (size_t)nblk] = t2;
+    }
+}
+
+// slot0 = (a1, b1), slot1 = (a2, b2) (optional)
+__global__ __launch_bounds__(RBLK) void k_dot2(const double* __restrict__ a1, const double* __restrict__ b1,
+                                               const double* __restrict__ a2, const double* __restrict__ b2,
+                                               size_t len, double* __restrict__ partials,
+                                               const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (active && !active[pair]) return;
+    size_t off = (size_t)pair * len;
+    double s0 = 0, s1 = 0;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+        s0 += a1[off + i] * b1[off + i];
+        if (a2) s1 += a2[off + i] * b2[off + i];
+    }
+    block_store_partials(s0, s1, 0.0, partials, a2 ? 2 : 1, gridDim.x, pair, blockIdx.x);
+}
+
+// p = r + beta (p - omega v)
+__global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const double* __restrict__ r,
+                                                   const double* __restrict__ v, size_t len,
+                                                   const PairScalars* __restrict__ sc,
+                                                   const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    double beta = sc[pair].beta, omega = sc[pair].omega;
+    size_t off = (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK)
+        p[off + i] = r[off + i] + beta * (p[off + i] - omega * v[off + i]);
+}
+
+// x += alpha y ; r -= alpha v (r becomes s) ; partial (s, s)
+__global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ x, const double* __restrict__ y,
+                                                   double* __restrict__ r, const double* __restrict__ v, size_t len,
+                                                   const PairScalars* __restrict__ sc, double* __restrict__ partials,
+                                                   const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    double alpha = sc[pair].alpha;
+    size_t off = (size_t)pair * len;
+    double ss = 0;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+        x[off + i] += alpha * y[off + i];
+        double s = r[off + i] - alpha * v[off + i];
+        r[off + i] = s;
+        ss += s * s;
+    }
+    block_store_partials(ss, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
+}
+
+// x += omega z ; r = s - omega t ; partial (r, r)
+__global__ __launch_bounds__(RBLK) void k_update_xr(double* __restrict__ x, const double* __restrict__ z,
+                                                    double* __restrict__ r, const double* __restrict__ t, size_t len,
+                                                    const PairScalars* __restrict__ sc, double* __restrict__ partials,
+                                                    const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    double omega = sc[pair].omega;
+    size_t off = (size_t)pair * len;
+    double rr = 0;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+        x[off + i] += omega * z[off + i];
+        double s = r[off + i] - omega * t[off + i];
+        r[off + i] = s;
+        rr += s * s;
+    }
+    block_store_partials(rr, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
+}
+
+__global__ void k_fill(double* __restrict__ x, size_t npts, double c0, double c1, double c2) {
+    int pair = blockIdx.y;
+    size_t len = 3 * npts, off = (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+        x[off + i] = i < npts ? c0 : (i < 2 * npts ? c1 : c2);
+}
+
+enum ScalarStep { S_BNORM = 0, S_R0, S_RHO, S_ALPHA, S_S, S_OMEGA, S_R, S_FINAL };
+
+__device__ __forceinline__ double sum_partials(const double* __restrict__ pp, int nblk) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += pp[i];
+    return wave_sum(s);
+}
+
+// One wave per pair: reduce the block partials in fixed order and advance the BiCGStab scalar state.
+template <int STEP>
+__global__ void k_scalar(PairScalars* __restrict__ sc, const double* __restrict__ partials, int nblk,
+                         int* __restrict__ active, double rtol, int max_it) {
+    int pair = blockIdx.x;
+    if (STEP != S_BNORM && STEP != S_FINAL && !active[pair]) return;
+    const double* pp = partials + (size_t)pair * 3 * nblk;
+    double a = sum_partials(pp, nblk);
+    double b = (STEP == S_OMEGA) ? sum_partials(pp + nblk, nblk) : 0.0;
+    if (threadIdx.x != 0) return;
+    PairScalars& s = sc[pair];
+    if (STEP == S_BNORM) {
+        s.bnorm2 = a;
+        s.tol2 = rtol * rtol * a;
+        s.rho = s.alpha = s.omega = 1.0;
+        s.beta = 0.0;
+        s.iterations = 0;
+        s.converged = 0;
+        s.breakdown = 0;
+        active[pair] = 1;
+    } else if (STEP == S_R0) {
+        s.rnorm2 = a;
+        if (a <= s.tol2) { s.converged = 1; active[pair] = 0; }
+        if (max_it <= 0) active[pair] = 0;
+    } else if (STEP == S_RHO) {
+        double beta = (a / s.rho) * (s.alpha / s.omega);
+        if (!(fabs(a) > 0.0) || !isfinite(beta)) { s.breakdown = 1; active[pair] = 0; return; }
+        s.beta = beta;
+        s.rho = a;
+    } else if (STEP == S_ALPHA) {
+        double alpha = s.rho / a;
+        if (!isfinite(alpha)) { s.breakdown = 1; active[pair] = 0; s.alpha = 0.0; return; }
+        s.alpha = alpha;
+    } else if (STEP == S_S) {
+        if (a <= s.tol2) {  // converged at the half step: x already holds x + alpha y
+            s.rnorm2 = a;
+            s.iterations += 1;
+            s.converged = 1;
+            active[pair] = 0;
+        }
+    } else if (STEP == S_OMEGA) {
+        double omega = a / b;
+        if (!isfinite(omega) || omega == 0.0) { s.breakdown = 1; s.omega = 0.0; }
+        else s.omega = omega;
+    } else if (STEP == S_R) {
+        s.rnorm2 = a;
+        s.iterations += 1;
+        if (a <= s.tol2) { s.converged = 1; active[pair] = 0; }
+        else if (s.breakdown || s.iterations >= max_it || !isfinite(a)) active[pair] = 0;
+    } else if (STEP == S_FINAL) {
+        s.rnorm2 = a;  // independent ||b - A x||^2 (OF.py:1151)
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Epilogue: interior solution -> full-grid outputs with the reference's mirror fix-up
+// (OF.py:1159-1166, rows then columns: corners end as x(2,2)-type values), unit scaling and speed
+// (OF.py:1189-1191).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_finalize(const double* __restrict__ x, int ni, int nj, double vscale,
+                                                 double* __restrict__ vx, double* __restrict__ vy,
+                                                 double* __restrict__ gm, double* __restrict__ speed) {
+    int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
+    int Ni = ni + 2, Nj = nj + 2;
+    if (i >= Ni || j >= Nj) return;
+    size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    size_t idx = (size_t)fold(i - 1, ni) * nj + fold(j - 1, nj);
+    double u = x[off + idx] * vscale, w = x[off + npts + idx] * vscale, g = x[off + 2 * npts + idx];
+    size_t o = (size_t)pair * Ni * Nj + (size_t)i * Nj + j;
+    vx[o] = u;
+    vy[o] = w;
+    gm[o] = g;
+    if (speed) speed[o] = sqrt(u * u + w * w);
+}
+
+// Functionals of OF.py:1167-1183 on the BC-fixed fields (velocities in pixels/frame).
+__global__ __launch_bounds__(RBLK) void k_functionals(const double* __restrict__ frames, size_t frame_stride, int Nj,
+                                                      int ni, int nj, double alpha, double beta, int quirks,
+                                                      const double* __restrict__ x, double* __restrict__ partials) {
+    int pair = blockIdx.y;
+    size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const double* xu = x + off;
+    const double* xw = xu + npts;
+    const double* xg = xw + npts;
+    const double* I = frames + (size_t)pair * frame_stride;
+    const double* J = I + frame_stride;
+    double sL = 0, sS = 0, sR = 0;
+    for (size_t t = (size_t)blockIdx.x * RBLK + threadIdx.x; t < npts; t += (size_t)gridDim.x * RBLK) {
+        int p = (int)(t / nj), q = (int)(t % nj);
+        PixCoef k = pix_coef(I, Nj, p, q, quirks);
+        double dt = J[(size_t)(p + 1) * Nj + q + 1] - k.P;
+        // BC-fixed field value at interior offset: plain fold (no corner factor)
+        int pm = fold(p - 1, ni), pp = fold(p + 1, ni), qm = fold(q - 1, nj), qp = fold(q + 1, nj);
+        size_t c = (size_t)p * nj + q;
+        size_t a_m = (size_t)pm * nj + q, a_p = (size_t)pp * nj + q;
+        size_t b_m = (size_t)p * nj + qm, b_p = (size_t)p * nj + qp;
+        double dux = (xu[a_p] - xu[a_m]) / 2, dwx = (xw[a_p] - xw[a_m]) / 2, dgx = (xg[a_p] - xg[a_m]) / 2;
+        double duy = quirks ? dux : (xu[b_p] - xu[b_m]) / 2;
+        double dwy = quirks ? dwx : (xw[b_p] - xw[b_m]) / 2;
+        double dgy = quirks ? dgx : (xg[b_p] - xg[b_m]) / 2;
+        double e = dt + xu[c] * k.Dx + xw[c] * k.Dy + k.P * dux + k.P * dwy - xg[c];
+        sL += e * e;
+        sS += dux * dux + duy * duy + dwx * dwx + dwy * dwy;
+        sR += dgx * dgx + dgy * dgy;
+    }
+    block_store_partials(sL, alpha * sS, beta * sR, partials, 3, gridDim.x, pair, blockIdx.x);
+}
+
+__global__ void k_sum3(const double* __restrict__ partials, int nblk, double* __restrict__ out3) {
+    int pair = blockIdx.x;
+    for (int s = 0; s < 3; ++s) {
+        double v = sum_partials(partials + ((size_t)pair * 3 + s) * nblk, nblk);
+        if (threadIdx.x == 0) out3[pair * 3 + s] = v;
+    }
+}
+
+}  // namespace vof

@@ -1,0 +1,161 @@
+"""Drop-in for the hot path of the reference module ``source/optical_flow.py``.
+
+``variational_optical_flow`` keeps the reference's signature and result dictionary
+(source/optical_flow.py:715-724, 1193-1205) so that ``analysis/analyse_variational_optical_flow.py``
+can call it unchanged; the per-pair scipy.sparse assembly + PETSc KSP solve (OF.py:833-1145) is
+replaced by the batched HIP solver in ``csrc/`` (BiCGStab + geometric multigrid).
+The solve always runs on an MI355X through libvof.so; there is no CPU path in this module.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import _native
+
+__all__ = ["variational_optical_flow", "make_fake_data_frame", "blur_movie", "format_elapsed_time",
+           "apply_constant_boundary_condition", "choose_pairs_in_flight"]
+
+
+def make_fake_data_frame(x_position, y_position, sigma=1.0, width=20.0, include_noise=False, dimension=1000):
+    """Synthetic Gaussian-hat frame, same arguments and return value as OF.py:376-423:
+    ``frame[i, j] = exp((-(x_i - x0)^2 - (y_j - y0)^2) / sigma^2)`` on ``linspace(0, width, dimension)``;
+    returns ``(frame, delta_x)``."""
+    x = np.linspace(0, width, dimension)
+    y = np.linspace(0, width, dimension)
+    frame = np.exp((-(x[:, None] - x_position) ** 2 - (y[None, :] - y_position) ** 2) / sigma ** 2)
+    delta_x = x[1] - x[0]
+    if include_noise:
+        frame = np.abs(frame + np.random.rand(dimension, dimension) * 0.0000001)
+    return frame, delta_x
+
+
+def blur_movie(movie, smoothing_sigma):
+    """Per-frame Gaussian blur (OF.py:282-306).  The reference calls
+    ``skimage.filters.gaussian(frame, sigma, preserve_range=True)``, which is
+    ``scipy.ndimage.gaussian_filter(frame, sigma, mode='nearest', truncate=4.0)``; it is a host
+    pre-processing step of the caller, outside the solver hot path."""
+    import scipy.ndimage
+    movie = np.asarray(movie)
+    blurred = np.zeros_like(movie, dtype="double")
+    for index in range(movie.shape[0]):
+        blurred[index] = scipy.ndimage.gaussian_filter(movie[index].astype(np.float64), smoothing_sigma,
+                                                       mode="nearest", truncate=4.0)
+    return blurred
+
+
+def format_elapsed_time(time_difference):
+    """(minutes, seconds, milliseconds) of a ``time.time()`` difference, OF.py:1212-1238."""
+    minutes = int(time_difference // 60)
+    seconds = int(time_difference % 60)
+    milliseconds = int((time_difference - int(time_difference)) * 1000)
+    return minutes, seconds, milliseconds
+
+
+def apply_constant_boundary_condition(image):
+    """In-place mirror of the border lines (OF.py:1304-1316): rows first, then columns."""
+    image[0, :] = image[2, :]
+    image[-1, :] = image[-3, :]
+    image[:, 0] = image[:, 2]
+    image[:, -1] = image[:, -3]
+
+
+def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=256):
+    """Largest batch of frame pairs whose workspace fits in ``memory_fraction`` of the free HBM."""
+    free, _total = _native.device_memory(device)
+    budget = free * memory_fraction
+    per_pair = _native.query_workspace(n_i, n_j, 1) + 5 * n_i * n_j * 8  # + host-API staging
+    return int(max(1, min(n_pairs, cap, budget // max(per_pair, 1))))
+
+
+def variational_optical_flow(movie,
+                             delta_x=1.0,
+                             delta_t=1.0,
+                             speed_alpha=1.0,
+                             remodelling_alpha=1000.0,
+                             smoothing_sigma=None,
+                             initial_v_x=0.0,
+                             initial_v_y=0.0,
+                             initial_remodelling=0.0,
+                             use_direct_solver=False,
+                             *,
+                             rtol=None,
+                             max_iterations=1000,
+                             reference_quirks=True,
+                             device=0,
+                             max_pairs_in_flight=None,
+                             coarse_precision="float64",
+                             verbose=False,
+                             return_stats=False):
+    """Variational optical flow with remodelling on an image stack, on one MI355X.
+
+    Positional/keyword arguments up to ``use_direct_solver`` have the reference's meaning
+    (OF.py:725-762).  ``movie`` is ``(T, N_i, N_j)``, any real dtype; the result ``k`` is the flow
+    from frame ``k`` to ``k+1``.  Returns the reference's result dict (OF.py:1193-1205): ``v_x``,
+    ``v_y``, ``speed``, ``remodelling`` (float64 ``(T-1, N_i, N_j)``), ``original_data``,
+    ``blurred_data``, ``delta_x``, ``delta_t``, ``converged`` (flag of the LAST pair, as in the
+    reference), ``L1_functional``, ``remodelling_functional``, ``speed_functional``.
+
+    Differences, all opt-in or invisible at the reference's tolerance:
+      * all pairs are solved concurrently from the same constant initial guess instead of
+        warm-starting pair k from pair k-1 (OF.py:803-806); the converged answer is the same to
+        solver tolerance;
+      * ``use_direct_solver=True`` (SuperLU in the reference, OF.py:1146-1147) is honoured as "solve
+        to rtol=1e-11" on the GPU;
+      * keyword-only extras: ``rtol`` (default 1e-6 = OF.py:1120), ``max_iterations`` (1000),
+        ``reference_quirks`` (True keeps OF.py:698-699 'dy'=='dx' and the OF.py:1205
+        ``speed_functional`` assignment), ``device``, ``max_pairs_in_flight``, ``coarse_precision``,
+        ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
+        converged / functionals).
+    """
+    movie = np.asarray(movie).astype(np.float64)                       # OF.py:769
+    if movie.ndim != 3:
+        raise ValueError("movie must be a 3-D array (frames, x, y)")
+    if smoothing_sigma is not None:                                     # OF.py:770-773
+        movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma)
+    else:
+        movie_to_analyse = movie
+    T, N_i, N_j = movie.shape
+    if T < 2:
+        raise ValueError("movie needs at least two frames")
+    if rtol is None:
+        rtol = 1e-11 if use_direct_solver else 1e-6
+    params = _native.default_params(
+        speed_alpha=float(speed_alpha), remodelling_alpha=float(remodelling_alpha), delta_x=float(delta_x),
+        delta_t=float(delta_t), initial_v_x=float(initial_v_x), initial_v_y=float(initial_v_y),
+        initial_remodelling=float(initial_remodelling), rtol=float(rtol), max_iterations=int(max_iterations),
+        reference_quirks=int(bool(reference_quirks)),
+        coarse_precision={"float64": 0, "float32": 1}[coarse_precision])
+    if max_pairs_in_flight is None:
+        max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
+    t0 = time.time()
+    with _native.Solver(N_i, N_j, max_pairs_in_flight, device=device) as solver:
+        v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+    if verbose:
+        m, s, ms = format_elapsed_time(time.time() - t0)
+        print(f"Elapsed time for solve: {m} minutes, {s} seconds, {ms} milliseconds")
+        for k in range(T - 1):
+            print(f"pair {k + 1}: iterations {stats['iterations'][k]}, relative residual "
+                  f"{stats['relative_residual'][k]:.3e}, converged {bool(stats['converged'][k])}")
+        if not stats["converged"].all():
+            print("the solver has not actually converged, the result will be incorrect or inaccurate")
+
+    result = dict()
+    result["v_x"] = v_x
+    result["v_y"] = v_y
+    result["speed"] = speed
+    result["remodelling"] = remodelling
+    result["original_data"] = movie
+    result["delta_x"] = delta_x
+    result["delta_t"] = delta_t
+    result["blurred_data"] = movie_to_analyse
+    result["converged"] = bool(stats["converged"][-1])                  # OF.py:1202: last pair only
+    result["L1_functional"] = float(np.sum(stats["L1_functional"]))
+    result["remodelling_functional"] = float(np.sum(stats["remodelling_functional"]))
+    # OF.py:1205 stores the remodelling sum under 'speed_functional'
+    result["speed_functional"] = (result["remodelling_functional"] if reference_quirks
+                                  else float(np.sum(stats["speed_functional"])))
+    if return_stats:
+        result["stats"] = stats
+    return result

@@ -1,0 +1,102 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/vof.h
+declares, struct layouts agree, and the product path fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from opticalflow_amd import build, _native
+    build.build_native(verbose=False)
+    return _native.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vof.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vof_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from opticalflow_amd import _native
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/vof.h but not exported by libvof.so"
+        assert s in _native.SIGNATURES, f"{s} has no ctypes prototype"
+    assert set(_native.SIGNATURES) == set(syms)
+
+
+def test_version_and_default_params(lib):
+    from opticalflow_amd import _native
+    assert lib.vof_version() == 100
+    p = _native.default_params()
+    # the reference's solver settings: OF.py:718-719, 1120
+    assert (p.speed_alpha, p.remodelling_alpha, p.rtol, p.max_iterations) == (1.0, 1000.0, 1e-6, 1000)
+    assert (p.nu_pre, p.nu_post, p.reference_quirks, p.coarse_precision) == (2, 2, 1, 0)
+    assert C.sizeof(_native.VofParams) == 8 * 8 + 8 * 4
+    assert C.sizeof(_native.VofPairStats) == 40
+    with pytest.raises(TypeError):
+        _native.default_params(no_such_field=1)
+
+
+def test_workspace_query(lib):
+    from opticalflow_amd import _native
+    one = _native.query_workspace(1024, 1024, 1)
+    assert 3e8 < one < 7e8                       # ~0.48 GB per 1024^2 pair
+    assert abs(_native.query_workspace(1024, 1024, 8) / one - 8) < 0.01
+    assert _native.query_workspace(3, 3, 1) == 0  # invalid size
+
+
+def test_kernel_names(lib):
+    from opticalflow_amd import _native
+    for i, n in enumerate(_native.K_NAMES):
+        assert lib.vof_kernel_name(i).decode() == n
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product path must raise, never silently compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from opticalflow_amd import optical_flow, _native
+    movie = np.random.default_rng(0).random((2, 16, 16))
+    with pytest.raises(_native.VofError):
+        optical_flow.variational_optical_flow(movie)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from opticalflow_amd import _native
+    with pytest.raises(_native.VofError, match="no CPU fallback"):
+        _native.load_library(str(tmp_path / "libvof_missing.so"))
+
+
+def test_product_path_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under opticalflow_amd/ or source/ may reference it."""
+    for base in ("opticalflow_amd", "source"):
+        for dirpath, _d, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_host_helpers_match_reference_semantics():
+    from opticalflow_amd import optical_flow as of
+    from conftest import load_golden
+    g = load_golden("g8_fake_frame.npz")
+    fr, dx = of.make_fake_data_frame(1.3, 2.9, sigma=1.7, width=6.0, dimension=37)
+    np.testing.assert_allclose(fr, g["frame"], rtol=4e-15)
+    assert dx == float(g["delta_x"])
+    g4 = load_golden("g4_blur_64.npz")
+    np.testing.assert_allclose(of.blur_movie(g4["movie"], 2.0), g4["blurred"], rtol=0, atol=1e-15)
+    assert of.format_elapsed_time(125.25) == (2, 5, 250)
+    a = np.arange(25.0).reshape(5, 5)
+    of.apply_constant_boundary_condition(a)
+    assert a[0, 0] == a[2, 2] and a[-1, -1] == a[2, 2] and a[0, 3] == a[2, 3]

@@ -1,0 +1,146 @@
+"""GPU tests of the solver's building blocks, each called through the C ABI (vof_debug_*) and
+compared with the independent numpy implementation in oracle/mg_prototype.py / oracle/vof_oracle.py.
+FP64 everywhere: tolerances are rounding-level (relative 1e-11 .. 1e-9)."""
+import numpy as np
+import pytest
+
+from oracle import vof_oracle as orc, mg_prototype as mg
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from opticalflow_amd import _native
+    _native.load_library()
+    return _native
+
+
+def make_case(kind, shape, npairs, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "texture":
+        n = max(shape)
+        mv = orc.make_texture_stack(n, npairs + 1, seed=seed)[:, :shape[0], :shape[1]]
+    else:
+        mv = rng.random((npairs + 1,) + shape) * 2.0
+    return np.ascontiguousarray(mv)
+
+
+CASES = [("random", (9, 11), 1, 2.5, 7.0, 1), ("random", (20, 37), 2, 1.0, 50.0, 2),
+         ("texture", (66, 66), 2, 1.0, 1e4, 3), ("texture", (50, 83), 1, 1.0, 1e4, 4)]
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES)
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_rhs_operator_smoother(native, kind, shape, npairs, alpha, beta, seed, quirks):
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, reference_quirks=quirks)
+    rng = np.random.default_rng(seed + 100)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        assert s.level_shape(0) == (shape[0] - 2, shape[1] - 2)
+        b = s.debug_rhs()
+        x = rng.standard_normal(b.shape)
+        y = s.debug_apply(0, x)
+        for k in range(npairs):
+            assert relerr(b[k], orc.rhs_interior(mv[k], mv[k + 1], bool(quirks))) < 1e-14
+            assert relerr(y[k], orc.apply_operator_interior(mv[k], x[k], alpha, beta, bool(quirks))) < 1e-13
+        if s.num_levels > 1:
+            # one colour at a time, against the serial numpy sweep in the same colour order
+            xg = x.copy()
+            xr = x.copy()
+            C = [mg.fine_stencil(mv[k], alpha, beta, bool(quirks)) for k in range(npairs)]
+            for colour in (0, 1, 2, 3, 3, 2, 1, 0):
+                xg = s.debug_gs(0, xg, b, colour)
+                for k in range(npairs):
+                    mg.gs_colour(C[k], xr[k], b[k], colour)
+                assert relerr(xg, xr) < 1e-11, colour
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES[1:])
+@pytest.mark.parametrize("coarse_precision", [0, 1])
+def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, beta, seed, coarse_precision):
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=coarse_precision)
+    tol = 1e-12 if coarse_precision == 0 else 2e-6
+    rng = np.random.default_rng(seed)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        H = [mg.Hierarchy(mv[k], alpha, beta) for k in range(npairs)]
+        assert s.num_levels == len(H[0].levels)
+        for lvl in range(s.num_levels):
+            assert s.level_shape(lvl) == tuple(H[0].levels[lvl].shape[-2:])
+        for lvl in range(1, s.num_levels):
+            Cg = s.debug_stencil(lvl)
+            for k in range(npairs):
+                assert relerr(Cg[k], H[k].levels[lvl]) < tol, lvl
+            # stored-stencil operator and smoother
+            x = rng.standard_normal((npairs, 3) + s.level_shape(lvl))
+            b = rng.standard_normal(x.shape)
+            y = s.debug_apply(lvl, x)
+            for k in range(npairs):
+                assert relerr(y[k], mg.apply_stencil(H[k].levels[lvl], x[k])) < max(tol, 1e-12)
+            if coarse_precision == 0:
+                xg, xr = x.copy(), x.copy()
+                for colour in (0, 1, 2, 3):
+                    xg = s.debug_gs(lvl, xg, b, colour)
+                    for k in range(npairs):
+                        mg.gs_colour(H[k].levels[lvl], xr[k], b[k], colour)
+                assert relerr(xg, xr) < 1e-9, lvl
+        # transfer operators on every level
+        for lvl in range(s.num_levels - 1):
+            fshape = (npairs, 3) + s.level_shape(lvl)
+            f = rng.standard_normal(fshape)
+            cg = s.debug_restrict(lvl, f)
+            cshape = cg.shape
+            for k in range(npairs):
+                assert relerr(cg[k], mg.restrict(f[k])) < 1e-13
+            e = rng.standard_normal(cshape)
+            fg = s.debug_prolong_add(lvl, f, e)
+            for k in range(npairs):
+                assert relerr(fg[k], f[k] + mg.prolong(e[k], *fshape[-2:])) < 1e-13
+        # coarsest dense solve
+        last = s.num_levels - 1
+        r = rng.standard_normal((npairs, 3) + s.level_shape(last))
+        eg = s.debug_coarse_solve(r)
+        for k in range(npairs):
+            er = (H[k].coarse_inv @ r[k].ravel()).reshape(r[k].shape)
+            assert relerr(eg[k], er) < (1e-8 if coarse_precision == 0 else 1e-3)
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES[1:3])
+def test_vcycle_matches_prototype(native, kind, shape, npairs, alpha, beta, seed):
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        r = s.debug_rhs()
+        e = s.debug_vcycle(r)
+        for k in range(npairs):
+            H = mg.Hierarchy(mv[k], alpha, beta)
+            assert relerr(e[k], H.vcycle(r[k], 2, 2)) < 1e-9
+
+
+def test_tiny_grid_single_level(native):
+    """6x7 image: the interior 4x5 grid is below the coarsening threshold -> dense solve only."""
+    from conftest import load_golden
+    g = load_golden("g2_matrix_6x7.npz")
+    p = native.default_params(speed_alpha=2.0, remodelling_alpha=3.0)
+    with native.Solver(6, 7, 1) as s:
+        s.debug_setup(g["movie"], p)
+        assert s.num_levels == 1
+        C = s.debug_stencil(0)
+        assert relerr(C[0], mg.fine_stencil(g["movie"][0], 2.0, 3.0)) < 1e-14
+
+
+def test_create_rejects_bad_arguments(native):
+    with pytest.raises(native.VofError, match="4x4"):
+        native.Solver(3, 10, 1)
+    with pytest.raises(native.VofError):
+        native.Solver(16, 16, 0)
+    with pytest.raises(native.VofError, match="device"):
+        native.Solver(16, 16, 1, device=99)

@@ -1,0 +1,207 @@
+"""GPU parity tests: the HIP solver, called through the drop-in Python entry point (which goes
+through the C ABI), against (1) the golden fixtures produced by the reference itself and (2) the
+CPU oracle on fresh seeded inputs.
+
+Tolerances; float64 end to end:
+  * tight solve (rtol 1e-10 / use_direct_solver=True): rel-L2 error <= 1e-7 per field versus the exact
+    solution of the reference-assembled system;
+  * the reference's own setting rtol = 1e-6: stopping rule met and rel-L2 error <= 1e-3 (the band any
+    converged PETSc bcgs run lies in).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_kwargs
+from oracle import vof_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-7
+LOOSE = 1e-3
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def of():
+    from opticalflow_amd import optical_flow
+    return optical_flow
+
+
+def check_fields(res, ref, tol, keys=("v_x", "v_y", "remodelling")):
+    for k in keys:
+        e = relerr(res[k], ref[k])
+        assert e < tol, (k, e)
+
+
+GOLDEN = ["g1_avof_simple_50.npz", "g2_matrix_6x7.npz", "g2b_matrix_9x11.npz", "g3_stack_32x48x4.npz",
+          "g7_texture_64x3.npz"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_tight(of, name):
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    res = of.variational_optical_flow(g["movie"], rtol=1e-10, return_stats=True, **kw)
+    check_fields(res, g, TIGHT)
+    assert res["stats"]["converged"].all()
+    assert res["stats"]["relative_residual"].max() < 1e-9
+    for key in ("L1_functional", "remodelling_functional", "speed_functional"):
+        assert res[key] == pytest.approx(float(g[key]), rel=1e-6, abs=1e-12), key
+    assert res["speed_functional"] == res["remodelling_functional"]      # OF.py:1205
+    if "speed" in g:
+        assert relerr(res["speed"], g["speed"]) < TIGHT
+    assert res["converged"] is True
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_reference_tolerance(of, name):
+    """The reference's own stopping rule rtol=1e-6 (OF.py:1120)."""
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    res = of.variational_optical_flow(g["movie"], return_stats=True, **kw)
+    st = res["stats"]
+    assert st["converged"].all()
+    assert st["relative_residual"].max() <= 1.5e-6
+    assert st["iterations"].max() <= 60
+    check_fields(res, g, LOOSE)
+
+
+def test_g1_printed_means(of):
+    """What the reference's enabled experiment prints (AVOF.py:58-66): expect ~0.1, 0.2, 0.05."""
+    g = load_golden("g1_avof_simple_50.npz")
+    res = of.variational_optical_flow(g["movie"], use_direct_solver=True, **golden_kwargs(g))
+    assert np.mean(res["v_x"]) == pytest.approx(1.049780578641995e-01, rel=1e-7)
+    assert np.mean(res["v_y"]) == pytest.approx(1.950243954755939e-01, rel=1e-7)
+    assert np.mean(res["remodelling"]) == pytest.approx(4.862204763997428e-02, rel=1e-7)
+    assert np.max(res["v_x"]) == pytest.approx(float(g["v_x"].max()), rel=1e-7)
+
+
+def test_blur_path(of):
+    g = load_golden("g4_blur_64.npz")
+    res = of.variational_optical_flow(g["movie"], rtol=1e-10, **golden_kwargs(g))
+    np.testing.assert_allclose(res["blurred_data"], g["blurred"], atol=1e-15)
+    check_fields(res, g, TIGHT)
+    assert res["original_data"].shape == g["movie"].shape
+
+
+def test_8bit_regime_uint8_input(of):
+    """uint8 stack, alpha=1e4, beta=1e2 (the harder regime T of SURVEY Appendix B)."""
+    g = load_golden("g6_8bit_64.npz")
+    assert g["movie"].dtype == np.uint8
+    res = of.variational_optical_flow(g["movie"], rtol=1e-10, return_stats=True, **golden_kwargs(g))
+    assert res["stats"]["converged"].all()
+    check_fields(res, g, 1e-6)
+    assert res["original_data"].dtype == np.float64
+
+
+def test_config1_gaussian_128x8(of):
+    """BASELINE config 1 (128x128x8 translating Gaussian) against the reference-generated crops."""
+    g = load_golden("g5_gaussian_128x8.npz")
+    movie, dx = orc.make_gaussian_stack(128, 8)
+    res = of.variational_optical_flow(movie, delta_x=dx, speed_alpha=1.0, remodelling_alpha=10000.0, rtol=1e-10,
+                                      return_stats=True)
+    c = slice(56, 72)
+    assert relerr(res["v_x"][:, c, c], g["v_x_crop"]) < TIGHT
+    assert relerr(res["v_y"][:, c, c], g["v_y_crop"]) < TIGHT
+    assert relerr(res["remodelling"][:, c, c], g["remodelling_crop"]) < TIGHT
+    assert relerr(res["v_y"][:, ::8, ::8], g["v_y_sub"]) < TIGHT
+    assert relerr(res["v_x"][:, :3, :], g["v_x_border"]) < TIGHT          # mirror-fixed border rows
+    np.testing.assert_allclose(res["remodelling"].mean(axis=(1, 2)), g["remodelling_mean"], rtol=1e-7)
+    assert res["L1_functional"] == pytest.approx(float(g["L1_functional"]), rel=1e-6)
+    assert res["stats"]["iterations"].max() <= 12
+
+
+@pytest.mark.parametrize("shape,alpha,beta,seed", [((40, 57), 1.0, 1e4, 5), ((33, 33), 3.0, 10.0, 6),
+                                                    ((4, 4), 1.0, 1.0, 7), ((5, 64), 1.0, 100.0, 8),
+                                                    ((130, 130), 1.0, 1e4, 9)])
+@pytest.mark.parametrize("quirks", [True, False])
+def test_fresh_inputs_against_oracle(of, shape, alpha, beta, seed, quirks):
+    """Seeded inputs the fixtures do not cover: ragged / minimal / odd sizes, quirk opt-out."""
+    n = max(shape)
+    if n >= 16:
+        movie = orc.make_texture_stack(n, 3, seed=seed)[:, :shape[0], :shape[1]]
+    else:
+        movie = np.random.default_rng(seed).random((3,) + shape)
+    ref = orc.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, delta_x=0.5, delta_t=2.0,
+                                       reference_quirks=quirks)
+    res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, delta_x=0.5, delta_t=2.0,
+                                      reference_quirks=quirks, rtol=1e-10, return_stats=True)
+    assert res["stats"]["converged"].all()
+    check_fields(res, ref, TIGHT, keys=("v_x", "v_y", "remodelling", "speed"))
+    for key in ("L1_functional", "remodelling_functional", "speed_functional"):
+        assert res[key] == pytest.approx(ref[key], rel=1e-6, abs=1e-12)
+    if not quirks:
+        assert res["speed_functional"] != res["remodelling_functional"]
+
+
+def test_batching_is_invisible(of):
+    """Chunked batches (max_pairs_in_flight < pairs) give the same result as one batch."""
+    movie = orc.make_texture_stack(48, 6, seed=21)
+    a = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, max_pairs_in_flight=5)
+    b = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, max_pairs_in_flight=2)
+    for k in ("v_x", "v_y", "remodelling", "speed"):
+        assert relerr(b[k], a[k]) < 1e-8
+    # and runs are bit-reproducible (deterministic reductions)
+    c = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, max_pairs_in_flight=5)
+    for k in ("v_x", "v_y", "remodelling"):
+        np.testing.assert_array_equal(a[k], c[k])
+
+
+def test_initial_guess_does_not_change_the_answer(of):
+    movie = orc.make_texture_stack(40, 2, seed=3)
+    a = of.variational_optical_flow(movie, remodelling_alpha=1e3, rtol=1e-11)
+    b = of.variational_optical_flow(movie, remodelling_alpha=1e3, rtol=1e-11, initial_v_x=0.4, initial_v_y=-0.3,
+                                    initial_remodelling=0.02, delta_x=1.0)
+    for k in ("v_x", "v_y", "remodelling"):
+        assert relerr(b[k], a[k]) < 1e-8
+
+
+def test_identical_frames_give_zero_flow(of):
+    fr = orc.make_texture_stack(32, 1, seed=1)[0]
+    res = of.variational_optical_flow(np.stack([fr, fr]), return_stats=True)
+    assert abs(res["v_x"]).max() == 0 and abs(res["remodelling"]).max() == 0
+    assert res["stats"]["iterations"][0] == 0 and res["converged"]
+
+
+def test_nonconvergence_is_reported_not_raised(of):
+    """max_iterations=1 cannot reach 1e-12: the reference only prints a warning (OF.py:1135-1138)."""
+    movie = orc.make_texture_stack(64, 2, seed=2)
+    res = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-13, max_iterations=1, return_stats=True)
+    assert res["converged"] is False
+    assert res["stats"]["iterations"][0] == 1
+    assert np.isfinite(res["v_x"]).all()
+
+
+def test_float32_coarse_stencils_same_answer(of):
+    movie = orc.make_texture_stack(96, 3, seed=4)
+    a = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, return_stats=True)
+    b = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, coarse_precision="float32",
+                                    return_stats=True)
+    assert b["stats"]["converged"].all()
+    for k in ("v_x", "v_y", "remodelling"):
+        assert relerr(b[k], a[k]) < 1e-8
+
+
+def test_medium_size_properties_512(of):
+    """512x512 (direct oracle impractical): independent residual, mirror structure, known flow."""
+    movie = orc.make_texture_stack(512, 3, seed=0)
+    res = of.variational_optical_flow(movie, remodelling_alpha=1e4, return_stats=True)
+    st = res["stats"]
+    assert st["converged"].all() and st["relative_residual"].max() <= 1.5e-6
+    assert st["iterations"].max() <= 12
+    for k in ("v_x", "v_y", "remodelling"):
+        f = res[k]
+        np.testing.assert_array_equal(f[:, 0, :], f[:, 2, :])
+        np.testing.assert_array_equal(f[:, -1, :], f[:, -3, :])
+        np.testing.assert_array_equal(f[:, :, 0], f[:, :, 2])
+        np.testing.assert_array_equal(f[:, :, -1], f[:, :, -3])
+    # exactly translating texture: true flow (0.3, 0.6) px/frame, gamma ~ 0
+    assert np.mean(res["v_x"]) == pytest.approx(0.3, abs=0.03)
+    assert np.mean(res["v_y"]) == pytest.approx(0.6, abs=0.03)
+    # independent residual through the CPU matrix-free operator on pair 0
+    xi = np.stack([res["v_x"][0], res["v_y"][0], res["remodelling"][0]])[:, 1:-1, 1:-1]
+    r = orc.rhs_interior(movie[0], movie[1]) - orc.apply_operator_interior(movie[0], xi, 1.0, 1e4)
+    assert np.linalg.norm(r) / np.linalg.norm(orc.rhs_interior(movie[0], movie[1])) <= 1.5e-6
