@@ -99,6 +99,8 @@ int vof_bench_sweeps_dev(vof_ctx* ctx, const double* movie, int n_pairs, const v
  * context's stream; totals are accumulated per kernel class and multigrid level. */
 int vof_profile_enable(vof_ctx* ctx, int on);
 int vof_profile_reset(vof_ctx* ctx);
+/* Restrict event recording to one kernel class / level (-1 = any); keeps the timed region light. */
+int vof_profile_filter(vof_ctx* ctx, int kernel_id, int level);
 /* level < 0: sum over levels.  Outputs: number of launches, total milliseconds. */
 int vof_profile_get(vof_ctx* ctx, int kernel_id, int level, int64_t* launches, double* total_ms);
 const char* vof_kernel_name(int kernel_id);

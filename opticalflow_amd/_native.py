@@ -55,6 +55,7 @@ SIGNATURES = {
     "vof_bench_sweeps_dev": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), C.c_int]),
     "vof_profile_enable": (C.c_int, [_vp, C.c_int]),
     "vof_profile_reset": (C.c_int, [_vp]),
+    "vof_profile_filter": (C.c_int, [_vp, C.c_int, C.c_int]),
     "vof_profile_get": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "vof_kernel_name": (C.c_char_p, [C.c_int]),
     "vof_debug_setup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams)]),
@@ -197,6 +198,10 @@ class Solver:
     # -- profiler
     def profile_enable(self, on=True):
         self._check(self.lib.vof_profile_enable(self.h, int(bool(on))), "profile_enable")
+
+    def profile_filter(self, kernel=-1, level=-1):
+        kid = K_NAMES.index(kernel) if isinstance(kernel, str) else int(kernel)
+        self._check(self.lib.vof_profile_filter(self.h, kid, level), "profile_filter")
 
     def profile_reset(self):
         self._check(self.lib.vof_profile_reset(self.h), "profile_reset")

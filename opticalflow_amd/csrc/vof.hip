@@ -71,6 +71,7 @@ struct vof_ctx {
     bool hierarchy_float = false;
     // profiler
     bool prof = false;
+    int prof_kid = -1, prof_level = -1;  // filter (-1 = any)
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
     long long prof_dropped = 0;
@@ -88,6 +89,8 @@ struct Prof {
     ProfRec rec;
     Prof(vof_ctx* c_, int kid, int level) : c(c_), on(false) {
         if (!c->prof) return;
+        if (c->prof_kid >= 0 && kid != c->prof_kid) return;
+        if (c->prof_level >= 0 && level != c->prof_level) return;
         if ((int)c->recs.size() >= MAX_PROF_RECS) { c->prof_dropped++; return; }
         if (c->free_events.size() >= 2) {
             rec.e0 = c->free_events.back(); c->free_events.pop_back();
@@ -631,6 +634,14 @@ int vof_profile_enable(vof_ctx* c, int on) {
     if (!c) return -1;
     if (!on) prof_collect(c);
     c->prof = on != 0;
+    return 0;
+}
+
+int vof_profile_filter(vof_ctx* c, int kid, int level) {
+    if (!c) return -1;
+    if (kid >= VOF_K_COUNT || level > 15) { c->err = "bad kernel id / level"; return -1; }
+    c->prof_kid = kid;
+    c->prof_level = level;
     return 0;
 }
 

@@ -133,7 +133,7 @@ def test_fresh_inputs_against_oracle(of, shape, alpha, beta, seed, quirks):
     check_fields(res, ref, TIGHT, keys=("v_x", "v_y", "remodelling", "speed"))
     for key in ("L1_functional", "remodelling_functional", "speed_functional"):
         assert res[key] == pytest.approx(ref[key], rel=1e-6, abs=1e-12)
-    if not quirks:
+    if not quirks and min(shape) > 4:   # (a 4x4 image is all mirror: every derivative vanishes)
         assert res["speed_functional"] != res["remodelling_functional"]
 
 
