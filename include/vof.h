@@ -103,6 +103,9 @@ int vof_profile_reset(vof_ctx* ctx);
 int vof_profile_filter(vof_ctx* ctx, int kernel_id, int level);
 /* level < 0: sum over levels.  Outputs: number of launches, total milliseconds. */
 int vof_profile_get(vof_ctx* ctx, int kernel_id, int level, int64_t* launches, double* total_ms);
+/* Sum over the recorded launches of the number of frame pairs each launch actually processed
+ * (converged pairs are skipped by later launches), i.e. the "units" of the roofline figure. */
+int vof_profile_get_units(vof_ctx* ctx, int kernel_id, int level, int64_t* pair_launches);
 const char* vof_kernel_name(int kernel_id);
 
 /* ---- debug / test entry points: single building blocks on device memory of the context -------

@@ -34,7 +34,7 @@ struct Level {
 
 struct ProfRec {
     hipEvent_t e0, e1;
-    int kid, level;
+    int kid, level, units;
 };
 
 }  // namespace
@@ -77,6 +77,8 @@ struct vof_ctx {
     long long prof_dropped = 0;
     double prof_ms[VOF_K_COUNT][16];
     long long prof_n[VOF_K_COUNT][16];
+    long long prof_units[VOF_K_COUNT][16];
+    int cur_units = 0;  // frame pairs the next launches process (active pairs of the batch)
 };
 
 static std::string g_create_error;
@@ -99,6 +101,7 @@ struct Prof {
             if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return;
         }
         rec.kid = kid; rec.level = level < 0 ? 0 : (level > 15 ? 15 : level);
+        rec.units = c->cur_units;
         on = true;
         hipEventRecord(rec.e0, c->stream);
     }
@@ -117,6 +120,7 @@ void prof_collect(vof_ctx* c) {
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             c->prof_ms[r.kid][r.level] += ms;
             c->prof_n[r.kid][r.level] += 1;
+            c->prof_units[r.kid][r.level] += r.units;
         }
         c->free_events.push_back(r.e0);
         c->free_events.push_back(r.e1);
@@ -297,6 +301,7 @@ namespace {
 int setup_batch(vof_ctx* c, const double* frames_dev, int np) {
     c->frames = frames_dev;
     c->npairs = np;
+    c->cur_units = np;
     int nl = (int)c->L.size();
     if (nl == 1) {
         Level& f = c->L[0];
@@ -359,6 +364,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         int nact = 0;
         for (int k = 0; k < np; ++k) nact += c->h_active[k] != 0;
         if (nact == 0) break;
+        c->cur_units = nact;
         const int* act = c->active;
         { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kr, nullptr, nullptr, len, c->partials, act); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_RHO><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
@@ -377,6 +383,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
     // independent residual (OF.py:1150-1151)
+    c->cur_units = np;
     apply_level(c, 0, c->kx, c->kb, c->kt, 1, np, nullptr);
     { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); }
     { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
@@ -502,6 +509,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     else { HIPCHK(hipStreamCreate(&c->stream)); c->own_stream = true; }
     memset(c->prof_ms, 0, sizeof c->prof_ms);
     memset(c->prof_n, 0, sizeof c->prof_n);
+    memset(c->prof_units, 0, sizeof c->prof_units);
     vof_default_params(&c->prm);
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
@@ -617,6 +625,7 @@ int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof
     HIPCHK(hipSetDevice(c->device));
     c->frames = movie;
     c->npairs = n_pairs;
+    c->cur_units = n_pairs;
     Level& f = c->L[0];
     {
         Prof pr(c, VOF_K_RHS, 0);
@@ -645,11 +654,23 @@ int vof_profile_filter(vof_ctx* c, int kid, int level) {
     return 0;
 }
 
+int vof_profile_get_units(vof_ctx* c, int kid, int level, int64_t* pair_launches) {
+    if (!c) return -1;
+    if (kid < 0 || kid >= VOF_K_COUNT || level > 15) { c->err = "bad kernel id / level"; return -1; }
+    prof_collect(c);
+    long long u = 0;
+    for (int l = 0; l < 16; ++l)
+        if (level < 0 || l == level) u += c->prof_units[kid][l];
+    if (pair_launches) *pair_launches = u;
+    return 0;
+}
+
 int vof_profile_reset(vof_ctx* c) {
     if (!c) return -1;
     prof_collect(c);
     memset(c->prof_ms, 0, sizeof c->prof_ms);
     memset(c->prof_n, 0, sizeof c->prof_n);
+    memset(c->prof_units, 0, sizeof c->prof_units);
     c->prof_dropped = 0;
     return 0;
 }

@@ -1,0 +1,82 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU host logic: pair-range sharding with one overlap
+frame, the all-gather re-assembly with uneven shards, and the reduction of the functionals.  The
+per-shard solver is injected (the CPU oracle) because the product solver needs a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from opticalflow_amd.distributed import shard_pair_range
+
+
+def test_shard_ranges_cover_all_pairs_once():
+    for P in (1, 2, 7, 63, 255, 1023):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                a, b = shard_pair_range(P, world, r)
+                assert 0 <= a <= b <= P
+                seen += list(range(a, b))
+            assert seen == list(range(P))
+            sizes = [shard_pair_range(P, world, r)[1] - shard_pair_range(P, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import vof_oracle as orc
+        from opticalflow_amd.distributed import variational_optical_flow_sharded
+        movie = orc.make_texture_stack(24, n_frames, seed=5)
+        calls = []
+
+        def solve_fn(sub, **kw):
+            calls.append(sub.shape[0])
+            return orc.variational_optical_flow(sub, **kw)
+
+        res = variational_optical_flow_sharded(movie, solve_fn=solve_fn, speed_alpha=1.0, remodelling_alpha=50.0,
+                                               delta_x=0.5, delta_t=1.0)
+        q.put((rank, calls, res["v_x"], res["remodelling"], res["L1_functional"], res["speed_functional"],
+               res["converged"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [4, 5, 2])
+def test_two_rank_gloo_sharded_solve_matches_single_process(n_frames):
+    from oracle import vof_oracle as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    movie = orc.make_texture_stack(24, n_frames, seed=5)
+    ref = orc.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=50.0, delta_x=0.5, delta_t=1.0)
+    P = n_frames - 1
+    for rank, calls, vx, gm, L1, sf, conv in got:
+        a, b = shard_pair_range(P, world, rank)
+        assert calls == ([b - a + 1] if b > a else [])       # shard + one overlap frame
+        assert vx.shape == ref["v_x"].shape
+        np.testing.assert_allclose(vx, ref["v_x"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gm, ref["remodelling"], rtol=1e-9, atol=1e-12)
+        assert L1 == pytest.approx(ref["L1_functional"], rel=1e-9)
+        assert sf == pytest.approx(ref["speed_functional"], rel=1e-9)
+        assert conv is True
