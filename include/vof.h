@@ -91,6 +91,10 @@ int vof_solve_stack_dev(vof_ctx* ctx, const double* movie, int n_frames, const v
                         double* v_x, double* v_y, double* remodelling, double* speed,
                         vof_pair_stats* stats);
 
+/* Smoother implementation: 1 (default) = fused streaming 4-colour sweep (one launch per sweep),
+ * 0 = one launch per colour (the simple reference kernels, kept for A/B tests). */
+int vof_set_fused_sweeps(vof_ctx* ctx, int on);
+
 /* Fixed-work kernel benchmark (SURVEY 8(d) "fixed sweep count"): n_sweeps full 4-colour block-GS
  * sweeps of the fine level on n_pairs pairs of a device-resident movie.  Used by bench.py. */
 int vof_bench_sweeps_dev(vof_ctx* ctx, const double* movie, int n_pairs, const vof_params* p, int n_sweeps);
@@ -116,6 +120,8 @@ int vof_debug_level_shape(vof_ctx* ctx, int level, int* n_i, int* n_j);
 int vof_debug_rhs(vof_ctx* ctx, double* b_host);                                   /* level 0 */
 int vof_debug_apply(vof_ctx* ctx, int level, const double* x_host, double* y_host); /* y = A_l x */
 int vof_debug_gs(vof_ctx* ctx, int level, double* x_host, const double* b_host, int colour);
+/* one full fused 4-colour sweep (reverse: colour order 3,2,1,0; from_zero: ignore x, start from 0) */
+int vof_debug_sweep(vof_ctx* ctx, int level, double* x_host, const double* b_host, int reverse, int from_zero);
 int vof_debug_restrict(vof_ctx* ctx, int level, const double* fine_host, double* coarse_host);
 int vof_debug_prolong_add(vof_ctx* ctx, int level, double* fine_host, const double* coarse_host);
 int vof_debug_stencil(vof_ctx* ctx, int level, double* c_host); /* [pair][81][n_i][n_j], level >= 1 */

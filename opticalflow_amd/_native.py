@@ -64,6 +64,8 @@ SIGNATURES = {
     "vof_debug_rhs": (C.c_int, [_vp, _vp]),
     "vof_debug_apply": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "vof_debug_gs": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int]),
+    "vof_debug_sweep": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
+    "vof_set_fused_sweeps": (C.c_int, [_vp, C.c_int]),
     "vof_debug_restrict": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "vof_debug_prolong_add": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "vof_debug_stencil": (C.c_int, [_vp, C.c_int, _vp]),
@@ -254,6 +256,15 @@ class Solver:
         b = np.ascontiguousarray(b, dtype=np.float64).reshape(self._vec(level))
         self._check(self.lib.vof_debug_gs(self.h, level, _ptr(x), _ptr(b), colour), "debug_gs")
         return x
+
+    def debug_sweep(self, level, x, b, reverse=False, from_zero=False):
+        x = np.array(x, dtype=np.float64, copy=True).reshape(self._vec(level))
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(self._vec(level))
+        self._check(self.lib.vof_debug_sweep(self.h, level, _ptr(x), _ptr(b), int(reverse), int(from_zero)), "debug_sweep")
+        return x
+
+    def set_fused_sweeps(self, on=True):
+        self._check(self.lib.vof_set_fused_sweeps(self.h, int(bool(on))), "set_fused_sweeps")
 
     def debug_restrict(self, level, fine):
         fine = np.ascontiguousarray(fine, dtype=np.float64).reshape(self._vec(level))

@@ -30,6 +30,7 @@ struct Level {
     double* x = nullptr; // levels >= 1
     double* b = nullptr; // levels >= 1
     double* r = nullptr; // residual scratch (all levels but the last)
+    double* x2 = nullptr; // ping-pong partner of x for the out-of-place fused sweeps
 };
 
 struct ProfRec {
@@ -69,6 +70,7 @@ struct vof_ctx {
     int npairs = 0;
     vof_params prm;
     bool hierarchy_float = false;
+    bool fused = true;   // fused streaming 4-colour sweeps (false: one launch per colour)
     // profiler
     bool prof = false;
     int prof_kid = -1, prof_level = -1;  // filter (-1 = any)
@@ -222,21 +224,82 @@ void coarse_solve(vof_ctx* c, const double* r, double* e, int np, const int* act
     k_coarse_solve<<<np, 256, c->nd * sizeof(double), c->stream>>>(c->invT, c->nd, r, e, active);
 }
 
+// One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
+void sweep_level(vof_ctx* c, int l, const double* x_in, double* x_out, const double* b, bool reverse, int np,
+                 const int* active) {
+    Level& lv = c->L[l];
+    int po = reverse ? 1 : 0;
+    int rows = lv.ni + po;
+    int nb = (rows + 127) / 128;                       // bands of <= 128 rows, balanced, even height
+    int TI = std::max(2, (((rows + nb - 1) / nb + 1) / 2) * 2);
+    dim3 g((lv.nj + po + SW_OUT - 1) / SW_OUT, (rows + TI - 1) / TI, np);
+    if (l == 0 && lv.C == nullptr) {
+        Prof p(c, VOF_K_GS0, 0);
+        SweepFine pol;
+        pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
+        pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
+        size_t lds = (size_t)(SW_RING * 3 * SW_W + SW_RING * SW_IW) * sizeof(double);
+        k_sweep<SweepFine><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+    } else {
+        Prof p(c, VOF_K_GS, l);
+        size_t lds = (size_t)(SW_RING * 3 * SW_W) * sizeof(double);
+        if (c->hierarchy_float && l > 0) {
+            SweepStored<float> pol; pol.C = (const float*)lv.C;
+            k_sweep<SweepStored<float>><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        } else {
+            SweepStored<double> pol; pol.C = (const double*)lv.C;
+            k_sweep<SweepStored<double>><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        }
+    }
+}
+
+// nu sweeps starting from `cur` (nullptr = zero guess); the result is guaranteed to end in `x`.
+void smooth_level(vof_ctx* c, int l, double* x, double* tmp, const double* b, int nu, bool from_zero, bool reverse,
+                  int np, const int* active) {
+    if (nu <= 0) {
+        if (from_zero) hipMemsetAsync(x, 0, (size_t)np * 3 * c->L[l].npts * sizeof(double), c->stream);
+        return;
+    }
+    // choose the first destination so that the last sweep writes into x
+    double* dst = (nu % 2 == 1) ? x : tmp;
+    const double* src = from_zero ? nullptr : x;
+    if (!from_zero && dst == x) {
+        // odd number of sweeps from x: first sweep must go x -> tmp; then an even number remains -> ends in tmp.
+        // Do x -> tmp, then (nu-1) sweeps ending in ... handle by one extra copy at the end.
+        dst = tmp;
+    }
+    for (int s = 0; s < nu; ++s) {
+        sweep_level(c, l, src, dst, b, reverse, np, active);
+        src = dst;
+        dst = (dst == x) ? tmp : x;
+    }
+    if (src != x)
+        hipMemcpyAsync(x, src, (size_t)np * 3 * c->L[l].npts * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+}
+
 // One V-cycle: x (zero initial guess) ~= A^-1 b.
 void vcycle(vof_ctx* c, int l, double* x, const double* b, int np, const int* active) {
     int last = (int)c->L.size() - 1;
     if (l == last) { coarse_solve(c, b, x, np, active); return; }
     Level& lv = c->L[l];
-    hipMemsetAsync(x, 0, (size_t)np * 3 * lv.npts * sizeof(double), c->stream);
-    for (int s = 0; s < c->prm.nu_pre; ++s)
-        for (int col = 0; col < 4; ++col) gs_colour(c, l, x, b, col, np, active);
+    if (c->fused) {
+        smooth_level(c, l, x, lv.x2, b, c->prm.nu_pre, true, false, np, active);
+    } else {
+        hipMemsetAsync(x, 0, (size_t)np * 3 * lv.npts * sizeof(double), c->stream);
+        for (int s = 0; s < c->prm.nu_pre; ++s)
+            for (int col = 0; col < 4; ++col) gs_colour(c, l, x, b, col, np, active);
+    }
     apply_level(c, l, x, b, lv.r, 1, np, active);
     Level& nx = c->L[l + 1];
     restrict_level(c, l, lv.r, nx.b, np, active);
     vcycle(c, l + 1, nx.x, nx.b, np, active);
     prolong_add_level(c, l, x, nx.x, np, active);
-    for (int s = 0; s < c->prm.nu_post; ++s)
-        for (int col = 3; col >= 0; --col) gs_colour(c, l, x, b, col, np, active);
+    if (c->fused) {
+        smooth_level(c, l, x, lv.x2, b, c->prm.nu_post, false, true, np, active);
+    } else {
+        for (int s = 0; s < c->prm.nu_post; ++s)
+            for (int col = 3; col >= 0; --col) gs_colour(c, l, x, b, col, np, active);
+    }
 }
 
 // Build the Galerkin hierarchy and the coarsest-level dense inverse for the current batch.
@@ -457,7 +520,7 @@ size_t vof_query_workspace(int n_i, int n_j, int B) {
     total += 8 * b * 3 * ni * nj;
     for (size_t l = 0; l < lv.size(); ++l) {
         size_t npts = lv[l].first * lv[l].second;
-        if (l + 1 < lv.size()) total += b * 3 * npts;
+        if (l + 1 < lv.size()) total += 2 * b * 3 * npts;
         if (l > 0) total += 2 * b * 3 * npts;
         if (l > 0 || lv.size() == 1) total += b * 81 * npts;
     }
@@ -526,6 +589,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     for (int l = 0; l < nl; ++l) {
         Level& lv = c->L[l];
         if (l + 1 < nl) if (int rc = dev_alloc(c, &lv.r, (size_t)B * 3 * lv.npts)) return rc;
+        if (l + 1 < nl) if (int rc = dev_alloc(c, &lv.x2, (size_t)B * 3 * lv.npts)) return rc;
         if (l > 0) {
             if (int rc = dev_alloc(c, &lv.x, (size_t)B * 3 * lv.npts)) return rc;
             if (int rc = dev_alloc(c, &lv.b, (size_t)B * 3 * lv.npts)) return rc;
@@ -632,8 +696,12 @@ int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof
         k_rhs<<<grid2d(f.ni, f.nj, n_pairs), blk2d, 0, c->stream>>>(movie, frame_stride(c), c->Nj, f.ni, f.nj, c->kb);
     }
     HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)n_pairs * 3 * f.npts * sizeof(double), c->stream));
-    for (int s = 0; s < n_sweeps; ++s)
-        for (int col = 0; col < 4; ++col) gs_colour(c, 0, c->kx, c->kb, col, n_pairs, nullptr);
+    if (c->fused) {
+        smooth_level(c, 0, c->kx, f.x2, c->kb, n_sweeps, true, false, n_pairs, nullptr);
+    } else {
+        for (int s = 0; s < n_sweeps; ++s)
+            for (int col = 0; col < 4; ++col) gs_colour(c, 0, c->kx, c->kb, col, n_pairs, nullptr);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -757,6 +825,24 @@ int vof_debug_gs(vof_ctx* c, int level, double* x_host, const double* b_host, in
     HIPCHK(hipMemcpyAsync(x_host, c->kp, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_debug_sweep(vof_ctx* c, int level, double* x_host, const double* b_host, int reverse, int from_zero) {
+    DBG_LEVEL(level)
+    if (level + 1 >= (int)c->L.size()) { c->err = "coarsest level has no smoother"; return -1; }
+    HIPCHK(hipMemcpyAsync(c->kp, x_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->kv, b_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    sweep_level(c, level, from_zero ? nullptr : c->kp, c->kt, c->kv, reverse != 0, c->npairs, nullptr);
+    HIPCHK(hipMemcpyAsync(x_host, c->kt, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vof_set_fused_sweeps(vof_ctx* c, int on) {
+    if (!c) return -1;
+    c->fused = on != 0;
     return 0;
 }
 

@@ -144,3 +144,65 @@ def test_create_rejects_bad_arguments(native):
         native.Solver(16, 16, 0)
     with pytest.raises(native.VofError, match="device"):
         native.Solver(16, 16, 1, device=99)
+
+
+SWEEP_CASES = [("random", (20, 37), 2, 1.0, 50.0, 2), ("texture", (66, 66), 2, 1.0, 1e4, 3),
+               ("texture", (50, 83), 1, 1.0, 1e4, 4), ("texture", (140, 270), 1, 1.0, 1e4, 5),
+               ("random", (12, 300), 1, 2.0, 5.0, 6), ("random", (263, 13), 1, 2.0, 5.0, 7)]
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", SWEEP_CASES)
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_fused_sweep_equals_colour_by_colour_order(native, kind, shape, npairs, alpha, beta, seed, quirks):
+    """The streaming fused sweep must reproduce the global colour order 0,1,2,3 (reverse: 3,2,1,0)
+    exactly - it is compared with the serial numpy sweep and, bit for bit, with the per-colour kernels."""
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, reference_quirks=quirks)
+    rng = np.random.default_rng(seed)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        b = s.debug_rhs()
+        x = rng.standard_normal(b.shape)
+        C = [mg.fine_stencil(mv[k], alpha, beta, bool(quirks)) for k in range(npairs)]
+        for reverse in (False, True):
+            for from_zero in (False, True):
+                xg = s.debug_sweep(0, x, b, reverse=reverse, from_zero=from_zero)
+                xr = np.zeros_like(x) if from_zero else x.copy()
+                xc = xr.copy()
+                for k in range(npairs):
+                    mg.smooth(C[k], xr[k], b[k], 1, reverse=reverse)
+                assert relerr(xg, xr) < 1e-11, (reverse, from_zero)
+                for colour in ((3, 2, 1, 0) if reverse else (0, 1, 2, 3)):
+                    xc = s.debug_gs(0, xc, b, colour)
+                np.testing.assert_array_equal(xg, xc)
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", SWEEP_CASES[1:4])
+@pytest.mark.parametrize("coarse_precision", [0, 1])
+def test_fused_sweep_on_stored_levels(native, kind, shape, npairs, alpha, beta, seed, coarse_precision):
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=coarse_precision)
+    rng = np.random.default_rng(seed)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        for lvl in range(1, s.num_levels - 1):
+            x = rng.standard_normal((npairs, 3) + s.level_shape(lvl))
+            b = rng.standard_normal(x.shape)
+            for reverse in (False, True):
+                xg = s.debug_sweep(lvl, x, b, reverse=reverse)
+                xc = x.copy()
+                for colour in ((3, 2, 1, 0) if reverse else (0, 1, 2, 3)):
+                    xc = s.debug_gs(lvl, xc, b, colour)
+                assert relerr(xg, xc) < 1e-13, (lvl, reverse)
+
+
+def test_vcycle_fused_equals_per_colour(native):
+    mv = make_case("texture", (130, 130), 2, 1.0, 1e4, 3)
+    p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4)
+    with native.Solver(130, 130, 2) as s:
+        s.debug_setup(mv, p)
+        r = s.debug_rhs()
+        e1 = s.debug_vcycle(r)
+        s.set_fused_sweeps(False)
+        e0 = s.debug_vcycle(r)
+        assert relerr(e1, e0) < 1e-12
