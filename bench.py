@@ -159,8 +159,9 @@ def main():
     dom = max(table, key=lambda r: r[3])
     if args.profile_table and rank == 0:
         for name, lvl, cnt, ms in sorted(table, key=lambda r: -r[3]):
+            gb = solver.profile_bytes(name, lvl) / 1e9
             print(f"  {name:13s} L{lvl:<2d} launches {cnt:7d}  total {ms:10.3f} ms  avg {1e3 * ms / cnt:9.2f} us  "
-                  f"{100 * ms / total_ms:5.1f}%", file=sys.stderr)
+                  f"{100 * ms / total_ms:5.1f}%  {gb / (ms * 1e-3) if gb else 0:8.0f} GB/s", file=sys.stderr)
     dom_name, dom_level = dom[0], dom[1]
     solver.profile_reset()
     solver.profile_filter(dom_name, dom_level)       # timed region: events only around the dominant kernel
@@ -183,10 +184,12 @@ def main():
     li, lj = solver.level_shape(dom_level)
     units = solver.profile_units(dom_name, dom_level)      # frame pairs actually processed, summed over launches
     pix_per_launch = (units / cnt) * li * lj if cnt else 0.0
+    alg_bytes = solver.profile_bytes(dom_name, dom_level)   # exact: summed by the library per launch
     solver.profile_enable(False)
     bpp = algorithmic_bytes_per_pixel(dom_name, coarse_bytes)
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
-    achieved = (bpp * pix_per_launch / avg_s) / 1e9 if (bpp and cnt) else None
+    bytes_per_launch = (alg_bytes / cnt) if (cnt and alg_bytes > 0) else (bpp * pix_per_launch if bpp else None)
+    achieved = (bytes_per_launch / avg_s) / 1e9 if (bytes_per_launch and cnt) else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -209,7 +212,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": f"{dom_name}@L{dom_level}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "launches": cnt, "pairs_per_launch": (units / cnt) if cnt else None, "avg_launch_us": 1e6 * avg_s if cnt else None,
-                     "algorithmic_bytes_per_launch": bpp * pix_per_launch if bpp else None,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
                      "share_of_gpu_time": dom[3] / total_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -110,6 +110,9 @@ int vof_profile_get(vof_ctx* ctx, int kernel_id, int level, int64_t* launches, d
 /* Sum over the recorded launches of the number of frame pairs each launch actually processed
  * (converged pairs are skipped by later launches), i.e. the "units" of the roofline figure. */
 int vof_profile_get_units(vof_ctx* ctx, int kernel_id, int level, int64_t* pair_launches);
+/* Sum over the recorded launches of their algorithmic bytes (bytes per pixel of DESIGN.md section 3 x
+ * level pixels x pairs processed); 0 for kernel classes that do not report it. */
+int vof_profile_get_bytes(vof_ctx* ctx, int kernel_id, int level, double* algorithmic_bytes);
 const char* vof_kernel_name(int kernel_id);
 
 /* ---- debug / test entry points: single building blocks on device memory of the context -------

@@ -58,6 +58,7 @@ SIGNATURES = {
     "vof_profile_filter": (C.c_int, [_vp, C.c_int, C.c_int]),
     "vof_profile_get": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "vof_profile_get_units": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "vof_profile_get_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "vof_kernel_name": (C.c_char_p, [C.c_int]),
     "vof_debug_setup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams)]),
     "vof_debug_level_shape": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -219,6 +220,12 @@ class Solver:
         kid = K_NAMES.index(kernel) if isinstance(kernel, str) else int(kernel)
         u = C.c_int64()
         self._check(self.lib.vof_profile_get_units(self.h, kid, level, C.byref(u)), "profile_get_units")
+        return u.value
+
+    def profile_bytes(self, kernel: int | str, level: int = -1):
+        kid = K_NAMES.index(kernel) if isinstance(kernel, str) else int(kernel)
+        u = C.c_double()
+        self._check(self.lib.vof_profile_get_bytes(self.h, kid, level, C.byref(u)), "profile_get_bytes")
         return u.value
 
     def profile_table(self):

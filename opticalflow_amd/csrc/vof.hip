@@ -36,6 +36,7 @@ struct Level {
 struct ProfRec {
     hipEvent_t e0, e1;
     int kid, level, units;
+    double bytes;  // algorithmic bytes of this launch (units x bytes per pair)
 };
 
 }  // namespace
@@ -80,6 +81,7 @@ struct vof_ctx {
     double prof_ms[VOF_K_COUNT][16];
     long long prof_n[VOF_K_COUNT][16];
     long long prof_units[VOF_K_COUNT][16];
+    double prof_bytes[VOF_K_COUNT][16];
     int cur_units = 0;  // frame pairs the next launches process (active pairs of the batch)
 };
 
@@ -91,7 +93,7 @@ struct Prof {
     vof_ctx* c;
     bool on;
     ProfRec rec;
-    Prof(vof_ctx* c_, int kid, int level) : c(c_), on(false) {
+    Prof(vof_ctx* c_, int kid, int level, double bytes_per_pair = 0.0) : c(c_), on(false) {
         if (!c->prof) return;
         if (c->prof_kid >= 0 && kid != c->prof_kid) return;
         if (c->prof_level >= 0 && level != c->prof_level) return;
@@ -104,6 +106,7 @@ struct Prof {
         }
         rec.kid = kid; rec.level = level < 0 ? 0 : (level > 15 ? 15 : level);
         rec.units = c->cur_units;
+        rec.bytes = bytes_per_pair * c->cur_units;
         on = true;
         hipEventRecord(rec.e0, c->stream);
     }
@@ -123,6 +126,7 @@ void prof_collect(vof_ctx* c) {
             c->prof_ms[r.kid][r.level] += ms;
             c->prof_n[r.kid][r.level] += 1;
             c->prof_units[r.kid][r.level] += r.units;
+            c->prof_bytes[r.kid][r.level] += r.bytes;
         }
         c->free_events.push_back(r.e0);
         c->free_events.push_back(r.e1);
@@ -166,12 +170,13 @@ inline size_t frame_stride(const vof_ctx* c) { return (size_t)c->Ni * c->Nj; }
 void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np, const int* active) {
     Level& lv = c->L[l];
     dim3 g = grid2d_colour(lv.ni, lv.nj, colour, np);
+    const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
     if (l == 0 && c->L.size() > 1) {
-        Prof p(c, VOF_K_GS0, 0);
+        Prof p(c, VOF_K_GS0, 0, 20.0 * lv.npts);
         k_gs0<<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->prm.speed_alpha,
                                           c->prm.remodelling_alpha, c->prm.reference_quirks, x, b, colour, active);
     } else {
-        Prof p(c, VOF_K_GS, l);
+        Prof p(c, VOF_K_GS, l, (81.0 * cb + 72.0) / 4.0 * lv.npts);
         if (c->hierarchy_float && l > 0)
             k_gs<float><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, colour, active);
         else
@@ -185,7 +190,7 @@ void apply_level(vof_ctx* c, int l, const double* x, const double* b, double* y,
     Level& lv = c->L[l];
     dim3 g = grid2d(lv.ni, lv.nj, np);
     if (l == 0 && lv.C == nullptr) {
-        Prof p(c, VOF_K_APPLY0, 0);
+        Prof p(c, VOF_K_APPLY0, 0, (mode ? 80.0 : 56.0) * lv.npts);
         if (mode)
             k_apply0<1><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
                                                     c->prm.speed_alpha, c->prm.remodelling_alpha,
@@ -195,8 +200,8 @@ void apply_level(vof_ctx* c, int l, const double* x, const double* b, double* y,
                                                     c->prm.speed_alpha, c->prm.remodelling_alpha,
                                                     c->prm.reference_quirks, x, b, y, active);
     } else {
-        Prof p(c, VOF_K_RESIDUAL, l);
         bool f = c->hierarchy_float && l > 0;
+        Prof p(c, VOF_K_RESIDUAL, l, (81.0 * (f ? 4.0 : 8.0) + 48.0 + (mode ? 24.0 : 0.0)) * lv.npts);
         if (f) {
             if (mode) k_apply<float, 1><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
             else k_apply<float, 0><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
@@ -209,13 +214,13 @@ void apply_level(vof_ctx* c, int l, const double* x, const double* b, double* y,
 
 void restrict_level(vof_ctx* c, int l, const double* fine, double* coarse, int np, const int* active) {
     Level &f = c->L[l], &k = c->L[l + 1];
-    Prof p(c, VOF_K_RESTRICT, l);
+    Prof p(c, VOF_K_RESTRICT, l, 24.0 * f.npts + 24.0 * k.npts);
     k_restrict<<<grid2d(k.ni, k.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
 }
 
 void prolong_add_level(vof_ctx* c, int l, double* fine, const double* coarse, int np, const int* active) {
     Level &f = c->L[l], &k = c->L[l + 1];
-    Prof p(c, VOF_K_PROLONG, l);
+    Prof p(c, VOF_K_PROLONG, l, 48.0 * f.npts + 24.0 * k.npts);
     k_prolong_add<<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
 }
 
@@ -234,14 +239,15 @@ void sweep_level(vof_ctx* c, int l, const double* x_in, double* x_out, const dou
     int TI = std::max(2, (((rows + nb - 1) / nb + 1) / 2) * 2);
     dim3 g((lv.nj + po + SW_OUT - 1) / SW_OUT, (rows + TI - 1) / TI, np);
     if (l == 0 && lv.C == nullptr) {
-        Prof p(c, VOF_K_GS0, 0);
+        Prof p(c, VOF_K_GS0, 0, (x_in ? 80.0 : 56.0) * lv.npts);   // I + b(3) + x(3) in, x(3) out
         SweepFine pol;
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
         pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
         size_t lds = (size_t)(SW_RING * 3 * SW_W + SW_RING * SW_IW) * sizeof(double);
         k_sweep<SweepFine><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
     } else {
-        Prof p(c, VOF_K_GS, l);
+        const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
+        Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 72.0 : 48.0)) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * SW_W) * sizeof(double);
         if (c->hierarchy_float && l > 0) {
             SweepStored<float> pol; pol.C = (const float*)lv.C;
@@ -344,7 +350,10 @@ __global__ __launch_bounds__(NT) void k_store_fine_stencil(const double* __restr
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q;
     PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
-    double* out = C + (size_t)pair * 81 * npts + idx;
+    const CLay L(ni, nj);
+    double* out = C + (size_t)pair * 81 * L.plane + L.idx(p, q);
+    (void)idx;
+    npts = L.plane;
     for (int oi = -1; oi <= 1; ++oi)
         for (int oj = -1; oj <= 1; ++oj) {
             double blk[9];
@@ -522,7 +531,7 @@ size_t vof_query_workspace(int n_i, int n_j, int B) {
         size_t npts = lv[l].first * lv[l].second;
         if (l + 1 < lv.size()) total += 2 * b * 3 * npts;
         if (l > 0) total += 2 * b * 3 * npts;
-        if (l > 0 || lv.size() == 1) total += b * 81 * npts;
+        if (l > 0 || lv.size() == 1) total += b * 81 * CLay((int)lv[l].first, (int)lv[l].second).plane;
     }
     size_t nd = 3 * lv.back().first * lv.back().second;
     total += b * nd * 2 * nd + b * nd * nd;
@@ -573,6 +582,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     memset(c->prof_ms, 0, sizeof c->prof_ms);
     memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_units, 0, sizeof c->prof_units);
+    memset(c->prof_bytes, 0, sizeof c->prof_bytes);
     vof_default_params(&c->prm);
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
@@ -596,7 +606,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
         }
         if (l > 0 || nl == 1) {
             double* C = nullptr;
-            if (int rc = dev_alloc(c, &C, (size_t)B * 81 * lv.npts)) return rc;
+            if (int rc = dev_alloc(c, &C, (size_t)B * 81 * CLay(lv.ni, lv.nj).plane)) return rc;
             lv.C = C;
         }
     }
@@ -733,12 +743,24 @@ int vof_profile_get_units(vof_ctx* c, int kid, int level, int64_t* pair_launches
     return 0;
 }
 
+int vof_profile_get_bytes(vof_ctx* c, int kid, int level, double* algorithmic_bytes) {
+    if (!c) return -1;
+    if (kid < 0 || kid >= VOF_K_COUNT || level > 15) { c->err = "bad kernel id / level"; return -1; }
+    prof_collect(c);
+    double u = 0;
+    for (int l = 0; l < 16; ++l)
+        if (level < 0 || l == level) u += c->prof_bytes[kid][l];
+    if (algorithmic_bytes) *algorithmic_bytes = u;
+    return 0;
+}
+
 int vof_profile_reset(vof_ctx* c) {
     if (!c) return -1;
     prof_collect(c);
     memset(c->prof_ms, 0, sizeof c->prof_ms);
     memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_units, 0, sizeof c->prof_units);
+    memset(c->prof_bytes, 0, sizeof c->prof_bytes);
     c->prof_dropped = 0;
     return 0;
 }
@@ -874,14 +896,23 @@ int vof_debug_prolong_add(vof_ctx* c, int level, double* fine_host, const double
 int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
     DBG_LEVEL(level)
     if (!lv.C) { c->err = "level has no stored stencil"; return -1; }
-    size_t n = (size_t)c->npairs * 81 * lv.npts;
+    const CLay L(lv.ni, lv.nj);
+    size_t n = (size_t)c->npairs * 81 * L.plane;
+    std::vector<double> tmp(n);
     if (c->hierarchy_float && level > 0) {
-        std::vector<float> tmp(n);
-        HIPCHK(hipMemcpy(tmp.data(), lv.C, n * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) c_host[i] = tmp[i];
+        std::vector<float> tf(n);
+        HIPCHK(hipMemcpy(tf.data(), lv.C, n * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) tmp[i] = tf[i];
     } else {
-        HIPCHK(hipMemcpy(c_host, lv.C, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tmp.data(), lv.C, n * sizeof(double), hipMemcpyDeviceToHost));
     }
+    // colour-split device layout -> row-major [pair][81][n_i][n_j]
+    for (int k = 0; k < c->npairs; ++k)
+        for (int pl = 0; pl < 81; ++pl)
+            for (int p = 0; p < lv.ni; ++p)
+                for (int q = 0; q < lv.nj; ++q)
+                    c_host[((size_t)k * 81 + pl) * lv.npts + (size_t)p * lv.nj + q] =
+                        tmp[((size_t)k * 81 + pl) * L.plane + L.idx(p, q)];
     return 0;
 }
 

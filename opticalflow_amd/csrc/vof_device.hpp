@@ -40,6 +40,18 @@ __device__ __forceinline__ double pweight(int f, int c, int nc) {
     return 0.0;
 }
 
+// Colour-split layout of a stored stencil plane: the four colour classes (p mod 2, q mod 2) are stored as four
+// contiguous sub-planes of (ni+1)/2 x (nj+1)/2 entries, so the points of one colour row are contiguous
+// (the fused sweep and the per-colour kernels read them with unit stride).
+struct CLay {
+    int hj;
+    size_t sub, plane;
+    __host__ __device__ CLay(int ni, int nj) : hj((nj + 1) / 2), sub((size_t)((ni + 1) / 2) * ((nj + 1) / 2)), plane(4 * sub) {}
+    __host__ __device__ __forceinline__ size_t idx(int p, int q) const {
+        return (size_t)(((p & 1) << 1) | (q & 1)) * sub + (size_t)(p >> 1) * hj + (q >> 1);
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // Image-derived coefficients of one interior pixel (OF.py:812-827).
 // ------------------------------------------------------------------------------------------
@@ -248,7 +260,8 @@ template <typename CT>
 __device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t npts, const double* __restrict__ x,
                                                 int ni, int nj, int p, int q, double& y0, double& y1, double& y2,
                                                 bool include_diag) {
-    size_t idx = (size_t)p * nj + q;
+    const CLay L(ni, nj);
+    const size_t idx = L.idx(p, q), cps = L.plane;
     y0 = y1 = y2 = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -261,10 +274,10 @@ __device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t
             if (!include_diag && a == 1 && bb == 1) continue;
             size_t t = (size_t)tp * nj + tq;
             double xu = x[t], xw = x[npts + t], xg = x[2 * npts + t];
-            const CT* cb = C + (size_t)((a * 3 + bb) * 9) * npts + idx;
-            y0 += (double)cb[0] * xu + (double)cb[npts] * xw + (double)cb[2 * npts] * xg;
-            y1 += (double)cb[3 * npts] * xu + (double)cb[4 * npts] * xw + (double)cb[5 * npts] * xg;
-            y2 += (double)cb[6 * npts] * xu + (double)cb[7 * npts] * xw + (double)cb[8 * npts] * xg;
+            const CT* cb = C + (size_t)((a * 3 + bb) * 9) * cps + idx;
+            y0 += (double)cb[0] * xu + (double)cb[cps] * xw + (double)cb[2 * cps] * xg;
+            y1 += (double)cb[3 * cps] * xu + (double)cb[4 * cps] * xw + (double)cb[5 * cps] * xg;
+            y2 += (double)cb[6 * cps] * xu + (double)cb[7 * cps] * xw + (double)cb[8 * cps] * xg;
         }
     }
 }
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(NT) void k_apply(const CT* __restrict__ C, int ni, 
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
     double y0, y1, y2;
-    stencil_offdiag<CT>(C + (size_t)pair * 81 * npts, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
+    stencil_offdiag<CT>(C + (size_t)pair * 81 * CLay(ni, nj).plane, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
     if (MODE == 1) {
         y0 = b[off + idx] - y0;
         y1 = b[off + npts + idx] - y1;
@@ -309,12 +322,14 @@ __global__ __launch_bounds__(NT) void k_gs(const CT* __restrict__ C, int ni, int
     int p = 2 * (blockIdx.y * BY + threadIdx.y) + (colour >> 1);
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
-    const CT* Cp = C + (size_t)pair * 81 * npts;
+    const CLay L(ni, nj);
+    const CT* Cp = C + (size_t)pair * 81 * L.plane;
     double y0, y1, y2;
     stencil_offdiag<CT>(Cp, npts, x + off, ni, nj, p, q, y0, y1, y2, false);
     double D[9];
+    const size_t cidx = L.idx(p, q);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) D[t] = (double)Cp[(size_t)(36 + t) * npts + idx];
+    for (int t = 0; t < 9; ++t) D[t] = (double)Cp[(size_t)(36 + t) * L.plane + cidx];
     double x0, x1, x2;
     solve3(D, b[off + idx] - y0, b[off + npts + idx] - y1, b[off + 2 * npts + idx] - y2, x0, x1, x2);
     x[off + idx] = x0;
@@ -407,7 +422,8 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
     if (cp >= nci || cq >= ncj) return;
     int a = off / 3 - 1, b = off % 3 - 1;
     int Dp = cp + a, Dq = cq + b;
-    size_t nf = (size_t)nfi * nfj, nc = (size_t)nci * ncj;
+    const CLay Lf(nfi, nfj), Lc(nci, ncj);
+    const size_t nf = Lf.plane, nc = Lc.plane;
     double acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.0;
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
                             for (int t = 0; t < 9; ++t) acc[t] += w * blk[t];
                         } else {
                             const CTF* cb = Cf + (size_t)pair * 81 * nf + (size_t)(((oi + 1) * 3 + (oj + 1)) * 9) * nf +
-                                            (size_t)fp * nfj + fq;
+                                            Lf.idx(fp, fq);
 #pragma unroll
                             for (int t = 0; t < 9; ++t) acc[t] += w * (double)cb[(size_t)t * nf];
                         }
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
             }
         }
     }
-    CTC* out = Cc + (size_t)pair * 81 * nc + (size_t)(off * 9) * nc + (size_t)cp * ncj + cq;
+    CTC* out = Cc + (size_t)pair * 81 * nc + (size_t)(off * 9) * nc + Lc.idx(cp, cq);
 #pragma unroll
     for (int t = 0; t < 9; ++t) out[(size_t)t * nc] = (CTC)(0.25 * acc[t]);
 }
@@ -467,14 +483,15 @@ __global__ void k_coarse_build(const CT* __restrict__ C, int ni, int nj, double*
         Wp[t] = (col == nd + row) ? 1.0 : 0.0;
     }
     __syncthreads();
-    const CT* Cp = C + (size_t)pair * 81 * npts;
+    const CLay L(ni, nj);
+    const CT* Cp = C + (size_t)pair * 81 * L.plane;
     for (int t = threadIdx.x; t < 81 * npts; t += blockDim.x) {
         int plane = t / npts, pt = t % npts;
         int ab = plane / 9, rc = plane % 9;
         int a = ab / 3 - 1, b = ab % 3 - 1, r = rc / 3, c = rc % 3;
         int p = pt / nj, q = pt % nj, tp = p + a, tq = q + b;
         if (tp < 0 || tp >= ni || tq < 0 || tq >= nj) continue;
-        Wp[(size_t)(r * npts + pt) * 2 * nd + (c * npts + tp * nj + tq)] = (double)Cp[t];
+        Wp[(size_t)(r * npts + pt) * 2 * nd + (c * npts + tp * nj + tq)] = (double)Cp[(size_t)plane * L.plane + L.idx(p, q)];
     }
 }
 
@@ -1001,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, 
 // ---- policy: stored Galerkin stencil (levels >= 1) -------------------------------------------
 template <typename CT>
 struct SweepStored {
-    const CT* C;  // [pair][81][npts]
+    const CT* C;  // [pair][81][colour-split plane]
     static constexpr bool kHasImage = false;
     // dummies so the kernel template compiles for both policies
     const double* frames = nullptr;
@@ -1011,8 +1028,9 @@ struct SweepStored {
     __device__ __forceinline__ void update(const SweepGeom& g, const double* xs, const double* /*im*/, int pair,
                                            int p, int q, int rr, int lc, double b0, double b1, double b2, double& u,
                                            double& w, double& gm) const {
-        const size_t npts = (size_t)g.ni * g.nj;
-        const CT* cp = C + (size_t)pair * 81 * npts + (size_t)p * g.nj + q;
+        const CLay L(g.ni, g.nj);
+        const size_t npts = L.plane;
+        const CT* cp = C + (size_t)pair * 81 * npts + L.idx(p, q);
         double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {

@@ -197,7 +197,7 @@ def test_fused_sweep_on_stored_levels(native, kind, shape, npairs, alpha, beta, 
 
 
 def test_vcycle_fused_equals_per_colour(native):
-    mv = make_case("texture", (130, 130), 2, 1.0, 1e4, 3)
+    mv = make_case("texture", (130, 130), 2, 3)
     p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4)
     with native.Solver(130, 130, 2) as s:
         s.debug_setup(mv, p)
