@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per rank (weak scaling)")
     ap.add_argument("--pairs-in-flight", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-6)
-    ap.add_argument("--coarse-precision", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--coarse-precision", default="float32", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel HIP-event table (stderr)")

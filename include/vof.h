@@ -41,7 +41,7 @@ typedef struct vof_params {
     int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction (default 2) */
     int32_t nu_post;           /* ... and after (default 2) */
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
-    int32_t coarse_precision;  /* 0: float64 Galerkin stencils (default); 1: float32 storage */
+    int32_t coarse_precision;  /* 1 (default): float32 storage of the Galerkin stencils; 0: float64 */
     int32_t reserved[3];
 } vof_params;
 

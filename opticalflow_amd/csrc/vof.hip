@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct vof_ctx {
     vof_params prm;
     bool hierarchy_float = false;
     bool fused = true;   // fused streaming 4-colour sweeps (false: one launch per colour)
+    bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
     // profiler
     bool prof = false;
     int prof_kid = -1, prof_level = -1;  // filter (-1 = any)
@@ -237,24 +239,29 @@ void sweep_level(vof_ctx* c, int l, const double* x_in, double* x_out, const dou
     int rows = lv.ni + po;
     int nb = (rows + 127) / 128;                       // bands of <= 128 rows, balanced, even height
     int TI = std::max(2, (((rows + nb - 1) / nb + 1) / 2) * 2);
-    dim3 g((lv.nj + po + SW_OUT - 1) / SW_OUT, (rows + TI - 1) / TI, np);
+    const bool geoB = (l > 0) ? c->geo_b_stored : c->geo_b_fine;
+    const int out = geoB ? GeoB::OUT : GeoA::OUT, W = geoB ? GeoB::W : GeoA::W, IW = geoB ? GeoB::IW : GeoA::IW;
+    dim3 g((lv.nj + (geoB ? 0 : po) + out - 1) / out, (rows + TI - 1) / TI, np);
     if (l == 0 && lv.C == nullptr) {
         Prof p(c, VOF_K_GS0, 0, (x_in ? 80.0 : 56.0) * lv.npts);   // I + b(3) + x(3) in, x(3) out
         SweepFine pol;
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
         pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
-        size_t lds = (size_t)(SW_RING * 3 * SW_W + SW_RING * SW_IW) * sizeof(double);
-        k_sweep<SweepFine><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        size_t lds = (size_t)(SW_RING * 3 * W + SW_RING * IW) * sizeof(double);
+        if (geoB) k_sweep<SweepFine, GeoB><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        else k_sweep<SweepFine, GeoA><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
     } else {
         const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
         Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 72.0 : 48.0)) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
-        size_t lds = (size_t)(SW_RING * 3 * SW_W) * sizeof(double);
+        size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(double);
         if (c->hierarchy_float && l > 0) {
             SweepStored<float> pol; pol.C = (const float*)lv.C;
-            k_sweep<SweepStored<float>><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<float>, GeoB><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            else k_sweep<SweepStored<float>, GeoA><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
         } else {
             SweepStored<double> pol; pol.C = (const double*)lv.C;
-            k_sweep<SweepStored<double>><<<g, 256, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<double>, GeoB><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            else k_sweep<SweepStored<double>, GeoA><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
         }
     }
 }
@@ -513,7 +520,7 @@ void vof_default_params(vof_params* p) {
     p->nu_pre = 2;
     p->nu_post = 2;
     p->reference_quirks = 1;
-    p->coarse_precision = 0;
+    p->coarse_precision = 1;       // float32 storage of the Galerkin stencils (preconditioner only)
 }
 
 const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -584,6 +591,10 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     memset(c->prof_units, 0, sizeof c->prof_units);
     memset(c->prof_bytes, 0, sizeof c->prof_bytes);
     vof_default_params(&c->prm);
+    if (const char* e = getenv("VOF_SWEEP_GEO")) {   // experiment switch: "AA", "AB" (default), "BA", "BB" = fine,stored
+        c->geo_b_fine = e[0] == 'B';
+        c->geo_b_stored = e[0] && e[1] == 'B';
+    }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
     c->L.push_back(l0);

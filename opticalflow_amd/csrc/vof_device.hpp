@@ -43,10 +43,15 @@ __device__ __forceinline__ double pweight(int f, int c, int nc) {
 // Colour-split layout of a stored stencil plane: the four colour classes (p mod 2, q mod 2) are stored as four
 // contiguous sub-planes of (ni+1)/2 x (nj+1)/2 entries, so the points of one colour row are contiguous
 // (the fused sweep and the per-colour kernels read them with unit stride).
+#ifndef CLAY_PAD
+#define CLAY_PAD 1088
+#endif
 struct CLay {
     int hj;
     size_t sub, plane;
-    __host__ __device__ CLay(int ni, int nj) : hj((nj + 1) / 2), sub((size_t)((ni + 1) / 2) * ((nj + 1) / 2)), plane(4 * sub) {}
+    // plane stride padded by 17 x 64 elements: keeps 256-B alignment and breaks the power-of-two stride between
+    // the 81 planes a wave reads concurrently (HBM channel conflicts)
+    __host__ __device__ CLay(int ni, int nj) : hj((nj + 1) / 2), sub((size_t)((ni + 1) / 2) * ((nj + 1) / 2)), plane(4 * sub + CLAY_PAD) {}
     __host__ __device__ __forceinline__ size_t idx(int p, int q) const {
         return (size_t)(((p & 1) << 1) | (q & 1)) * sub + (size_t)(p >> 1) * hj + (q >> 1);
     }
@@ -820,14 +825,24 @@ __global__ void k_sum3(const double* __restrict__ partials, int nblk, double* __
 // LDS: columns are stored parity-split (even columns first) so the stride-2 accesses of a colour are
 // contiguous (no bank conflicts).
 // ==========================================================================================
-constexpr int SW_W = 128;     // strip width in LDS (halo included)
-constexpr int SW_OUT = 120;   // output columns per strip
-constexpr int SW_HALO = 4;
+constexpr int SW_HALO = 4;    // halo columns each side
 constexpr int SW_RING = 12;   // rows in the LDS ring
-constexpr int SW_IW = 132;    // image strip width (130 used, parity halves of 66)
 
-__device__ __forceinline__ int sw_cs(int lc) { return ((lc & 1) << 6) | (lc >> 1); }          // x ring column slot
-__device__ __forceinline__ int sw_ci(int lci) { return (lci & 1) * (SW_IW / 2) + (lci >> 1); }  // image ring column slot
+// Two strip geometries:
+//  GeoA: 4 waves, 128 columns in LDS, 120 owned; every colour wave also recomputes the halo columns it needs
+//        (column ranges shrink by one per colour).  Best for level 0 (no coefficient planes, 3 blocks/CU).
+//  GeoB: 128 owned columns, 128-column aligned, so the coefficient rows of the colour-split stencil planes are
+//        read in whole aligned cache lines; a 5th wave recomputes the six halo points.  For the stored levels.
+struct GeoA {
+    static constexpr int OUT = 120, W = 128, IW = 132, THREADS = 256;
+    static constexpr bool HALO_WAVE = false;
+};
+struct GeoB {
+    static constexpr int OUT = 128, W = 136, IW = 140, THREADS = 320;
+    static constexpr bool HALO_WAVE = true;
+};
+template <class G> __device__ __forceinline__ int sw_cs(int lc) { return (lc & 1) * (G::W / 2) + (lc >> 1); }
+template <class G> __device__ __forceinline__ int sw_ci(int lci) { return (lci & 1) * (G::IW / 2) + (lci >> 1); }
 __device__ __forceinline__ int sw_slot(int rr) { return (rr + 2 * SW_RING) % SW_RING; }
 
 struct SweepGeom {
@@ -846,14 +861,16 @@ struct SweepFine {
     static constexpr bool kHasImage = true;
 
     // new values of point (p, q) at relative row rr / local column lc; xs = x ring, im = image ring
+    template <class G>
     __device__ __forceinline__ void update(const SweepGeom& g, const double* xs, const double* im, int pair, int p,
                                            int q, int rr, int lc, double b0, double b1, double b2, double& u,
                                            double& w, double& gm) const {
         // image neighbourhood (full-image rows p..p+2, cols q..q+2  <->  ring rows rr-1..rr+1, cols lc..lc+2)
+        constexpr int SW_W = G::W, SW_IW = G::IW;
         const double* r0 = im + sw_slot(rr - 1) * SW_IW;
         const double* r1 = im + sw_slot(rr) * SW_IW;
         const double* r2 = im + sw_slot(rr + 1) * SW_IW;
-        int c0 = sw_ci(lc), c1 = sw_ci(lc + 1), c2 = sw_ci(lc + 2);
+        int c0 = sw_ci<G>(lc), c1 = sw_ci<G>(lc + 1), c2 = sw_ci<G>(lc + 2);
         double imm = r0[c0], im0 = r0[c1], imp = r0[c2];
         double i0m = r1[c0], i00 = r1[c1], i0p = r1[c2];
         double ipm = r2[c0], ip0 = r2[c1], ipp = r2[c2];
@@ -876,7 +893,7 @@ struct SweepFine {
                 if (di == 0 && dj == 0) continue;
                 int tq = q + dj;
                 bool oj = (tq < 0) || (tq >= g.nj);
-                int cc = sw_cs(fold(tq, g.nj) - g.qs);
+                int cc = sw_cs<G>(fold(tq, g.nj) - g.qs);
                 double s = (oi && oj) ? 2.0 : 1.0;
                 int t = (di + 1) * 3 + (dj + 1);
                 n.u[t] = s * row[cc];
@@ -896,10 +913,11 @@ struct SweepFine {
     }
 };
 
-template <class Pol>
-__global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, int po,
+template <class Pol, class G>
+__global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po,
                                                const double* __restrict__ x_in, double* __restrict__ x_out,
                                                const double* __restrict__ b, const int* __restrict__ active) {
+    constexpr int SW_W = G::W, SW_IW = G::IW, SW_OUT = G::OUT, SW_THREADS = G::THREADS;
     extern __shared__ double sw_lds[];
     double* xs = sw_lds;                            // [SW_RING][3][SW_W]
     double* im = sw_lds + SW_RING * 3 * SW_W;       // [SW_RING][SW_IW]   (only if Pol::kHasImage)
@@ -909,7 +927,8 @@ __global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, 
     SweepGeom g;
     g.ni = ni; g.nj = nj; g.TI = TI;
     g.p0 = blockIdx.y * TI - po;
-    const int q0 = blockIdx.x * SW_OUT - po;
+    // GeoB: strips always 128-aligned, po only swaps the column parity of the stages.  GeoA: strip origin shifted by po.
+    const int q0 = G::HALO_WAVE ? blockIdx.x * SW_OUT : blockIdx.x * SW_OUT - po;
     g.qs = q0 - SW_HALO;
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     const double* xin = x_in ? x_in + off : nullptr;
@@ -918,19 +937,40 @@ __global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, 
     const double* img = nullptr;
     if (Pol::kHasImage) img = pol.frames + (size_t)pair * pol.frame_stride;
 
-    // per-wave stage: colour = wave; row offset and column range of the stage
-    const int stage_row_off = (wave == 0) ? 0 : (wave == 1) ? -2 : (wave == 2) ? -5 : -7;
-    const int lc = 2 * lane + (wave & 1);                     // colours 1, 3 own the odd columns
-    const int lc_lo = 2 + wave, lc_hi = SW_W - 2 - wave;      // 2..126, 3..125, 4..124, 5..123
+    // stage of this lane: waves 0-3 own colour = wave on the 128 owned columns; wave 4 recomputes the six halo
+    // points (colour 0 at local columns 2, 132, 134; colour 1 at 3, 133; colour 2 at 132) that the owned columns
+    // of the later colours depend on.
+    int stage = wave, lc;
+    bool lane_on = true;
+    if (G::HALO_WAVE) {
+        // column parity of stage c is (c & 1) ^ po; for po = 1 the halo pattern is the mirror image
+        lc = SW_HALO + 2 * lane + ((wave & 1) ^ po);
+        if (wave == 4) {
+            const int hs[6] = {0, 0, 0, 1, 1, 2};
+            const int hl[6] = {2, SW_HALO + SW_OUT, SW_HALO + SW_OUT + 2, 3, SW_HALO + SW_OUT + 1, SW_HALO + SW_OUT};
+            lane_on = lane < 6;
+            stage = hs[lane_on ? lane : 0];
+            lc = hl[lane_on ? lane : 0];
+            if (po) lc = SW_W - 1 - lc;
+        }
+    } else {
+        // every colour wave covers its whole parity class of the strip; valid ranges 2..126, 3..125, 4..124, 5..123
+        lc = 2 * lane + (wave & 1);
+        lane_on = (lc >= 2 + wave) && (lc <= SW_W - 2 - wave);
+    }
+    const int stage_row_off = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
     const int q = g.qs + lc;
-    const bool col_ok = (lc >= lc_lo) && (lc <= lc_hi) && (q >= 0) && (q < nj);
-    const int rr_lo = (wave < 2) ? 0 : 1, rr_hi = (wave < 2) ? TI : TI - 1;
+    const bool col_ok = lane_on && (q >= 0) && (q < nj);
+    const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
 
-    // element mapping of the cooperative load-in / write-out: 2 rows x 3 fields x 128 columns
+    // element mapping of the cooperative load-in / write-out: 2 rows x 3 fields x SW_W columns
     int m_row[3], m_f[3], m_lc[3];
+    bool m_on[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        int idx = tid + 256 * k;
+        int idx = tid + SW_THREADS * k;
+        m_on[k] = idx < 2 * 3 * SW_W;
+        idx = m_on[k] ? idx : 0;
         m_row[k] = idx / (3 * SW_W);
         m_f[k] = (idx % (3 * SW_W)) / SW_W;
         m_lc[k] = idx % SW_W;
@@ -944,28 +984,29 @@ __global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, 
         for (int k = 0; k < 3; ++k) {
             int rr = e - 10 + m_row[k];
             int p = g.p0 + rr, qq = g.qs + m_lc[k];
-            if (rr >= 0 && rr < TI && p >= 0 && p < ni && m_lc[k] >= SW_HALO && m_lc[k] < SW_HALO + SW_OUT &&
-                qq >= 0 && qq < nj)
-                xout[(size_t)m_f[k] * npts + (size_t)p * nj + qq] = xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs(m_lc[k])];
+            if (m_on[k] && rr >= 0 && rr < TI && p >= 0 && p < ni && m_lc[k] >= SW_HALO &&
+                m_lc[k] < SW_HALO + SW_OUT && qq >= 0 && qq < nj)
+                xout[(size_t)m_f[k] * npts + (size_t)p * nj + qq] = xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs<G>(m_lc[k])];
         }
         // (2) global loads of relative rows e+2, e+3 into registers
-        double lx[3], li[2];
+        double lx[3], li[2] = {0.0, 0.0};
+        constexpr int NIMG = 2 * (SW_W + 2);                       // image elements per step (2 rows)
+        constexpr int KIMG = (NIMG + SW_THREADS - 1) / SW_THREADS;  // 1 (GeoB) or 2 (GeoA)
         const bool do_load = (e + 2 <= TI + 1);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             int rr = e + 2 + m_row[k];
             int p = g.p0 + rr, qq = g.qs + m_lc[k];
             lx[k] = 0.0;
-            if (do_load && xin && p >= 0 && p < ni && qq >= 0 && qq < nj)
+            if (do_load && m_on[k] && xin && p >= 0 && p < ni && qq >= 0 && qq < nj)
                 lx[k] = xin[(size_t)m_f[k] * npts + (size_t)p * nj + qq];
         }
         if (Pol::kHasImage) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                int idx = tid + 256 * k;
-                li[k] = 0.0;
-                if (idx < 2 * 130) {
-                    int rr = e + 2 + idx / 130, lci = idx % 130;
+            for (int k = 0; k < KIMG; ++k) {
+                int idx = tid + SW_THREADS * k;
+                if (idx < NIMG) {
+                    int rr = e + 2 + idx / (SW_W + 2), lci = idx % (SW_W + 2);
                     int fr = g.p0 + rr + 1, fc = g.qs + lci;      // full-image row / column
                     if (do_load && fr >= 0 && fr <= ni + 1 && fc >= 0 && fc <= nj + 1)
                         li[k] = img[(size_t)fr * pol.Nj + fc];
@@ -988,8 +1029,8 @@ __global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, 
             int p = g.p0 + rr;
             if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
                 double u, w, gm;
-                pol.update(g, xs, im, pair, p, q, rr, lc, b0, b1, b2, u, w, gm);
-                double* row = xs + sw_slot(rr) * 3 * SW_W + sw_cs(lc);
+                pol.template update<G>(g, xs, im, pair, p, q, rr, lc, b0, b1, b2, u, w, gm);
+                double* row = xs + sw_slot(rr) * 3 * SW_W + sw_cs<G>(lc);
                 row[0] = u; row[SW_W] = w; row[2 * SW_W] = gm;
             }
         }
@@ -998,15 +1039,15 @@ __global__ __launch_bounds__(256) void k_sweep(Pol pol, int ni, int nj, int TI, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 int rr = e + 2 + m_row[k];
-                xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs(m_lc[k])] = lx[k];
+                if (m_on[k]) xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs<G>(m_lc[k])] = lx[k];
             }
             if (Pol::kHasImage) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    int idx = tid + 256 * k;
-                    if (idx < 2 * 130) {
-                        int rr = e + 2 + idx / 130, lci = idx % 130;
-                        im[sw_slot(rr) * SW_IW + sw_ci(lci)] = li[k];
+                for (int k = 0; k < KIMG; ++k) {
+                    int idx = tid + SW_THREADS * k;
+                    if (idx < NIMG) {
+                        int rr = e + 2 + idx / (SW_W + 2), lci = idx % (SW_W + 2);
+                        im[sw_slot(rr) * SW_IW + sw_ci<G>(lci)] = li[k];
                     }
                 }
             }
@@ -1025,9 +1066,11 @@ struct SweepStored {
     size_t frame_stride = 0;
     int Nj = 0;
 
+    template <class G>
     __device__ __forceinline__ void update(const SweepGeom& g, const double* xs, const double* /*im*/, int pair,
                                            int p, int q, int rr, int lc, double b0, double b1, double b2, double& u,
                                            double& w, double& gm) const {
+        constexpr int SW_W = G::W;
         const CLay L(g.ni, g.nj);
         const size_t npts = L.plane;
         const CT* cp = C + (size_t)pair * 81 * npts + L.idx(p, q);
@@ -1038,7 +1081,7 @@ struct SweepStored {
 #pragma unroll
             for (int bb = 0; bb < 3; ++bb) {
                 if (a == 1 && bb == 1) continue;
-                int cc = sw_cs(lc + bb - 1);
+                int cc = sw_cs<G>(lc + bb - 1);
                 double xu = row[cc], xw = row[SW_W + cc], xg = row[2 * SW_W + cc];
                 const CT* cb = cp + (size_t)((a * 3 + bb) * 9) * npts;
                 y0 += (double)cb[0] * xu + (double)cb[npts] * xw + (double)cb[2 * npts] * xg;

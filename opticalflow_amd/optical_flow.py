@@ -85,7 +85,7 @@ def variational_optical_flow(movie,
                              reference_quirks=True,
                              device=0,
                              max_pairs_in_flight=None,
-                             coarse_precision="float64",
+                             coarse_precision="float32",
                              verbose=False,
                              return_stats=False):
     """Variational optical flow with remodelling on an image stack, on one MI355X.

@@ -115,7 +115,7 @@ def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, be
 @pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES[1:3])
 def test_vcycle_matches_prototype(native, kind, shape, npairs, alpha, beta, seed):
     mv = make_case(kind, shape, npairs, seed)
-    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0)
     with native.Solver(shape[0], shape[1], npairs) as s:
         s.debug_setup(mv, p)
         r = s.debug_rhs()
