@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--pairs-in-flight", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="float32", choices=["float64", "float32"])
+    ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel HIP-event table (stderr)")
@@ -130,7 +131,8 @@ def main():
     free, total = _native.device_memory(local_rank)
     B = args.pairs_in_flight or largest_batch(P, per_pair, 0.7 * free)
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
-                                    coarse_precision={"float64": 0, "float32": 1}[args.coarse_precision])
+                                    coarse_precision={"float64": 0, "float32": 1}[args.coarse_precision],
+                                    vcycle_precision={"float64": 0, "float32": 1}[args.vcycle_precision])
     solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
@@ -204,7 +206,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n}x{n}x{T} synthetic translating texture per GPU (seed {seed}), speed_alpha=1, "
                                f"remodelling_alpha=1e4, rtol={args.rtol:g}, all {P} pairs solved to the stopping rule",
-                   "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision,
+                   "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
                    "allgather": gathered is not None,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),

@@ -28,10 +28,11 @@ struct Level {
     int ni = 0, nj = 0;
     size_t npts = 0;
     void* C = nullptr;   // stored stencil [B][81][npts] (double or float); level 0: only for 1-level grids
-    double* x = nullptr; // levels >= 1
-    double* b = nullptr; // levels >= 1
-    double* r = nullptr; // residual scratch (all levels but the last)
-    double* x2 = nullptr; // ping-pong partner of x for the out-of-place fused sweeps
+    // V-cycle vectors; element type is float or double (ctx->vfloat), allocations are sized for double
+    void* x = nullptr;  // levels >= 1
+    void* b = nullptr;  // levels >= 1
+    void* r = nullptr;  // residual scratch (all levels but the last)
+    void* x2 = nullptr; // ping-pong partner of x for the out-of-place fused sweeps
 };
 
 struct ProfRec {
@@ -48,8 +49,10 @@ struct vof_ctx {
     bool own_stream = false;
     int Ni = 0, Nj = 0, B = 0;
     std::vector<Level> L;
-    double *kx = nullptr, *kb = nullptr, *kr = nullptr, *krh = nullptr, *kp = nullptr, *kv = nullptr, *kt = nullptr,
-           *ky = nullptr;
+    double *kx = nullptr, *kb = nullptr, *kr = nullptr, *krh = nullptr, *kp = nullptr, *kv = nullptr, *kt = nullptr;
+    double* ky = nullptr;   // V-cycle output y / z (V-typed: float when vfloat)
+    double* b32 = nullptr;  // V-typed copy of the V-cycle right-hand side (p or s) when vfloat
+    bool vfloat = false;    // V-cycle vectors stored as float32 (arithmetic stays FP64)
     double* partials = nullptr;
     int nblk = 0;
     PairScalars* sc = nullptr;
@@ -168,7 +171,15 @@ const dim3 blk2d(BX, BY, 1);
 
 inline size_t frame_stride(const vof_ctx* c) { return (size_t)c->Ni * c->Nj; }
 
-// ---------------------------------------------------------------- level kernels (dispatch on precision)
+// ---------------------------------------------------------------- level kernels
+// VT = storage type of the V-cycle vectors (float when ctx->vfloat, else double).
+#define VDISPATCH(c, ...)                                   \
+    do {                                                    \
+        if ((c)->vfloat) { using VT = float; __VA_ARGS__; } \
+        else { using VT = double; __VA_ARGS__; }            \
+    } while (0)
+
+// one colour, in place, one launch per colour: the simple reference smoother (double vectors only)
 void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np, const int* active) {
     Level& lv = c->L[l];
     dim3 g = grid2d_colour(lv.ni, lv.nj, colour, np);
@@ -186,54 +197,81 @@ void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np
     }
 }
 
-// y = A_l x (mode 0) or y = b - A_l x (mode 1)
-void apply_level(vof_ctx* c, int l, const double* x, const double* b, double* y, int mode, int np,
-                 const int* active) {
+// y = A_l x (mode 0) or y = b - A_l x (mode 1); XT/BT/YT storage types (level 0 matrix-free),
+// stored levels use one type for all three.
+template <typename XT, typename BT, typename YT>
+void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np, const int* active) {
+    Level& lv = c->L[0];
+    dim3 g = grid2d(lv.ni, lv.nj, np);
+    const double bytes = (8.0 + 3.0 * sizeof(XT) + 3.0 * sizeof(YT) + (mode ? 3.0 * sizeof(BT) : 0.0)) * lv.npts;
+    Prof p(c, VOF_K_APPLY0, 0, bytes);
+    if (mode)
+        k_apply0<1, XT, BT, YT><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
+                                                            c->prm.speed_alpha, c->prm.remodelling_alpha,
+                                                            c->prm.reference_quirks, x, b, y, active);
+    else
+        k_apply0<0, XT, BT, YT><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
+                                                            c->prm.speed_alpha, c->prm.remodelling_alpha,
+                                                            c->prm.reference_quirks, x, b, y, active);
+}
+
+template <typename VT>
+void apply_stored_t(vof_ctx* c, int l, const VT* x, const VT* b, VT* y, int mode, int np, const int* active) {
     Level& lv = c->L[l];
     dim3 g = grid2d(lv.ni, lv.nj, np);
-    if (l == 0 && lv.C == nullptr) {
-        Prof p(c, VOF_K_APPLY0, 0, (mode ? 80.0 : 56.0) * lv.npts);
-        if (mode)
-            k_apply0<1><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
-                                                    c->prm.speed_alpha, c->prm.remodelling_alpha,
-                                                    c->prm.reference_quirks, x, b, y, active);
-        else
-            k_apply0<0><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
-                                                    c->prm.speed_alpha, c->prm.remodelling_alpha,
-                                                    c->prm.reference_quirks, x, b, y, active);
+    bool f = c->hierarchy_float && l > 0;
+    Prof p(c, VOF_K_RESIDUAL, l, (81.0 * (f ? 4.0 : 8.0) + (mode ? 9.0 : 6.0) * sizeof(VT)) * lv.npts);
+    if (f) {
+        if (mode) k_apply<float, 1, VT><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
+        else k_apply<float, 0, VT><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
     } else {
-        bool f = c->hierarchy_float && l > 0;
-        Prof p(c, VOF_K_RESIDUAL, l, (81.0 * (f ? 4.0 : 8.0) + 48.0 + (mode ? 24.0 : 0.0)) * lv.npts);
-        if (f) {
-            if (mode) k_apply<float, 1><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
-            else k_apply<float, 0><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
-        } else {
-            if (mode) k_apply<double, 1><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
-            else k_apply<double, 0><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
-        }
+        if (mode) k_apply<double, 1, VT><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
+        else k_apply<double, 0, VT><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
     }
 }
 
-void restrict_level(vof_ctx* c, int l, const double* fine, double* coarse, int np, const int* active) {
-    Level &f = c->L[l], &k = c->L[l + 1];
-    Prof p(c, VOF_K_RESTRICT, l, 24.0 * f.npts + 24.0 * k.npts);
-    k_restrict<<<grid2d(k.ni, k.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
+// V-cycle internal operator application on level l (all vectors VT)
+template <typename VT>
+void apply_level_t(vof_ctx* c, int l, const VT* x, const VT* b, VT* y, int mode, int np, const int* active) {
+    if (l == 0 && c->L[0].C == nullptr) apply_fine_t<VT, VT, VT>(c, x, b, y, mode, np, active);
+    else apply_stored_t<VT>(c, l, x, b, y, mode, np, active);
 }
 
-void prolong_add_level(vof_ctx* c, int l, double* fine, const double* coarse, int np, const int* active) {
-    Level &f = c->L[l], &k = c->L[l + 1];
-    Prof p(c, VOF_K_PROLONG, l, 48.0 * f.npts + 24.0 * k.npts);
-    k_prolong_add<<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
+// Krylov-level products on level 0 with FP64 results: out = A y (y V-typed) and out = b - A x (all double)
+void krylov_apply(vof_ctx* c, const void* y, double* out, int np, const int* active) {
+    if (c->L[0].C) { apply_stored_t<double>(c, 0, (const double*)y, nullptr, out, 0, np, active); return; }
+    if (c->vfloat) apply_fine_t<float, double, double>(c, (const float*)y, nullptr, out, 0, np, active);
+    else apply_fine_t<double, double, double>(c, (const double*)y, nullptr, out, 0, np, active);
+}
+void residual_d(vof_ctx* c, const double* x, const double* b, double* out, int np, const int* active) {
+    if (c->L[0].C) apply_stored_t<double>(c, 0, x, b, out, 1, np, active);
+    else apply_fine_t<double, double, double>(c, x, b, out, 1, np, active);
 }
 
-void coarse_solve(vof_ctx* c, const double* r, double* e, int np, const int* active) {
+template <typename VT>
+void restrict_level_t(vof_ctx* c, int l, const VT* fine, VT* coarse, int np, const int* active) {
+    Level &f = c->L[l], &k = c->L[l + 1];
+    Prof p(c, VOF_K_RESTRICT, l, 3.0 * sizeof(VT) * (f.npts + k.npts));
+    k_restrict<VT><<<grid2d(k.ni, k.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
+}
+
+template <typename VT>
+void prolong_add_level_t(vof_ctx* c, int l, VT* fine, const VT* coarse, int np, const int* active) {
+    Level &f = c->L[l], &k = c->L[l + 1];
+    Prof p(c, VOF_K_PROLONG, l, 3.0 * sizeof(VT) * (2 * f.npts + k.npts));
+    k_prolong_add<VT><<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
+}
+
+template <typename VT>
+void coarse_solve_t(vof_ctx* c, const VT* r, VT* e, int np, const int* active) {
     Prof p(c, VOF_K_COARSE_SOLVE, (int)c->L.size() - 1);
-    k_coarse_solve<<<np, 256, c->nd * sizeof(double), c->stream>>>(c->invT, c->nd, r, e, active);
+    k_coarse_solve<VT><<<np, 256, c->nd * sizeof(double), c->stream>>>(c->invT, c->nd, r, e, active);
 }
 
 // One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
-void sweep_level(vof_ctx* c, int l, const double* x_in, double* x_out, const double* b, bool reverse, int np,
-                 const int* active) {
+template <typename VT>
+void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
+                   const int* active) {
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
     int rows = lv.ni + po;
@@ -242,77 +280,75 @@ void sweep_level(vof_ctx* c, int l, const double* x_in, double* x_out, const dou
     const bool geoB = (l > 0) ? c->geo_b_stored : c->geo_b_fine;
     const int out = geoB ? GeoB::OUT : GeoA::OUT, W = geoB ? GeoB::W : GeoA::W, IW = geoB ? GeoB::IW : GeoA::IW;
     dim3 g((lv.nj + (geoB ? 0 : po) + out - 1) / out, (rows + TI - 1) / TI, np);
+    const double vs = sizeof(VT);
     if (l == 0 && lv.C == nullptr) {
-        Prof p(c, VOF_K_GS0, 0, (x_in ? 80.0 : 56.0) * lv.npts);   // I + b(3) + x(3) in, x(3) out
+        Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // I + b(3) + x(3) in, x(3) out
         SweepFine pol;
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
         pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
-        size_t lds = (size_t)(SW_RING * 3 * W + SW_RING * IW) * sizeof(double);
-        if (geoB) k_sweep<SweepFine, GeoB><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
-        else k_sweep<SweepFine, GeoA><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double);
+        if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
     } else {
         const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
-        Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 72.0 : 48.0)) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
-        size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(double);
+        Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
+        size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
         if (c->hierarchy_float && l > 0) {
             SweepStored<float> pol; pol.C = (const float*)lv.C;
-            if (geoB) k_sweep<SweepStored<float>, GeoB><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
-            else k_sweep<SweepStored<float>, GeoA><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
         } else {
             SweepStored<double> pol; pol.C = (const double*)lv.C;
-            if (geoB) k_sweep<SweepStored<double>, GeoB><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
-            else k_sweep<SweepStored<double>, GeoA><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
         }
     }
 }
 
-// nu sweeps starting from `cur` (nullptr = zero guess); the result is guaranteed to end in `x`.
-void smooth_level(vof_ctx* c, int l, double* x, double* tmp, const double* b, int nu, bool from_zero, bool reverse,
-                  int np, const int* active) {
+// nu sweeps (from a zero guess if from_zero, else from x); the result is guaranteed to end in `x`.
+template <typename VT>
+void smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
+                    const int* active) {
+    const size_t bytes = (size_t)np * 3 * c->L[l].npts * sizeof(VT);
     if (nu <= 0) {
-        if (from_zero) hipMemsetAsync(x, 0, (size_t)np * 3 * c->L[l].npts * sizeof(double), c->stream);
+        if (from_zero) hipMemsetAsync(x, 0, bytes, c->stream);
         return;
     }
-    // choose the first destination so that the last sweep writes into x
-    double* dst = (nu % 2 == 1) ? x : tmp;
-    const double* src = from_zero ? nullptr : x;
-    if (!from_zero && dst == x) {
-        // odd number of sweeps from x: first sweep must go x -> tmp; then an even number remains -> ends in tmp.
-        // Do x -> tmp, then (nu-1) sweeps ending in ... handle by one extra copy at the end.
-        dst = tmp;
+    if (!c->fused) {   // reference path: one launch per colour, in place (double vectors only)
+        if (from_zero) hipMemsetAsync(x, 0, bytes, c->stream);
+        for (int s = 0; s < nu; ++s)
+            for (int k = 0; k < 4; ++k)
+                gs_colour(c, l, (double*)x, (const double*)b, reverse ? 3 - k : k, np, active);
+        return;
     }
+    // out-of-place fused sweeps: choose the first destination so that the last sweep writes into x
+    const VT* src = from_zero ? nullptr : x;
+    VT* dst = (from_zero && (nu % 2 == 1)) ? x : tmp;
     for (int s = 0; s < nu; ++s) {
-        sweep_level(c, l, src, dst, b, reverse, np, active);
+        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active);
         src = dst;
         dst = (dst == x) ? tmp : x;
     }
-    if (src != x)
-        hipMemcpyAsync(x, src, (size_t)np * 3 * c->L[l].npts * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    if (src != x) hipMemcpyAsync(x, src, bytes, hipMemcpyDeviceToDevice, c->stream);
 }
 
 // One V-cycle: x (zero initial guess) ~= A^-1 b.
-void vcycle(vof_ctx* c, int l, double* x, const double* b, int np, const int* active) {
+template <typename VT>
+void vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) {
     int last = (int)c->L.size() - 1;
-    if (l == last) { coarse_solve(c, b, x, np, active); return; }
+    if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return; }
     Level& lv = c->L[l];
-    if (c->fused) {
-        smooth_level(c, l, x, lv.x2, b, c->prm.nu_pre, true, false, np, active);
-    } else {
-        hipMemsetAsync(x, 0, (size_t)np * 3 * lv.npts * sizeof(double), c->stream);
-        for (int s = 0; s < c->prm.nu_pre; ++s)
-            for (int col = 0; col < 4; ++col) gs_colour(c, l, x, b, col, np, active);
-    }
-    apply_level(c, l, x, b, lv.r, 1, np, active);
     Level& nx = c->L[l + 1];
-    restrict_level(c, l, lv.r, nx.b, np, active);
-    vcycle(c, l + 1, nx.x, nx.b, np, active);
-    prolong_add_level(c, l, x, nx.x, np, active);
-    if (c->fused) {
-        smooth_level(c, l, x, lv.x2, b, c->prm.nu_post, false, true, np, active);
-    } else {
-        for (int s = 0; s < c->prm.nu_post; ++s)
-            for (int col = 3; col >= 0; --col) gs_colour(c, l, x, b, col, np, active);
-    }
+    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, c->prm.nu_pre, true, false, np, active);
+    apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
+    restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
+    vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
+    prolong_add_level_t<VT>(c, l, x, (const VT*)nx.x, np, active);
+    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, c->prm.nu_post, false, true, np, active);
+}
+
+void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
+    VDISPATCH(c, vcycle_t<VT>(c, 0, (VT*)x, (const VT*)b, np, active));
 }
 
 // Build the Galerkin hierarchy and the coarsest-level dense inverse for the current batch.
@@ -429,7 +465,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         HIPCHK(hipMemcpyAsync(c->kr, c->kb, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
     } else {
         { Prof p(c, VOF_K_VECTOR, 0); k_fill<<<dim3(c->nblk, np), 256, 0, s>>>(c->kx, f.npts, P.initial_v_x * sx, P.initial_v_y * sx, P.initial_remodelling); }
-        apply_level(c, 0, c->kx, c->kb, c->kr, 1, np, nullptr);
+        residual_d(c, c->kx, c->kb, c->kr, np, nullptr);
     }
     HIPCHK(hipMemcpyAsync(c->krh, c->kr, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemsetAsync(c->kp, 0, (size_t)np * len * sizeof(double), s));
@@ -445,25 +481,30 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         if (nact == 0) break;
         c->cur_units = nact;
         const int* act = c->active;
-        { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kr, nullptr, nullptr, len, c->partials, act); }
+        { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kr, nullptr, nullptr, len, c->partials, act); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_RHO><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
-        { Prof p(c, VOF_K_VECTOR, 0); k_update_p<<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act); }
-        vcycle(c, 0, c->ky, c->kp, np, act);                       // y = M p
-        apply_level(c, 0, c->ky, nullptr, c->kv, 0, np, act);      // v = A y
-        { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); }
+        void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
+        void* vrhs_s = c->vfloat ? (void*)c->b32 : (void*)c->kr;
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));
+          VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
+        vcycle(c, c->ky, vrhs_p, np, act);                         // y = M p
+        krylov_apply(c, c->ky, c->kv, np, act);                    // v = A y
+        { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
-        { Prof p(c, VOF_K_VECTOR, 0); k_update_s<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->ky, c->kr, c->kv, len, c->sc, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5 + (c->vfloat ? 8.0 : 8.0) * len);
+          VDISPATCH(c, (k_update_s<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, c->kr, c->kv, len, c->sc, c->partials, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_S><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
-        vcycle(c, 0, c->ky, c->kr, np, act);                       // z = M s
-        apply_level(c, 0, c->ky, nullptr, c->kt, 0, np, act);      // t = A z
-        { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); }
+        vcycle(c, c->ky, vrhs_s, np, act);                         // z = M s
+        krylov_apply(c, c->ky, c->kt, np, act);                    // t = A z
+        { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
-        { Prof p(c, VOF_K_VECTOR, 0); k_update_xr<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->ky, c->kr, c->kt, len, c->sc, c->partials, act); }
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5 + (c->vfloat ? 4.0 : 8.0) * len);
+          VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, c->kr, c->kt, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
     // independent residual (OF.py:1150-1151)
     c->cur_units = np;
-    apply_level(c, 0, c->kx, c->kb, c->kt, 1, np, nullptr);
+    residual_d(c, c->kx, c->kb, c->kt, np, nullptr);
     { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); }
     { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
@@ -497,7 +538,10 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->nu_pre < 0 || p->nu_post < 0 || p->nu_pre + p->nu_post == 0) { c->err = "nu_pre + nu_post must be > 0"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
+    if (p->vcycle_precision != 0 && p->vcycle_precision != 1) { c->err = "vcycle_precision must be 0 or 1"; return -1; }
     c->prm = *p;
+    // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
+    c->vfloat = p->vcycle_precision == 1 && c->fused && c->L.size() > 1;
     return 0;
 }
 
@@ -521,6 +565,7 @@ void vof_default_params(vof_params* p) {
     p->nu_post = 2;
     p->reference_quirks = 1;
     p->coarse_precision = 1;       // float32 storage of the Galerkin stencils (preconditioner only)
+    p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)
 }
 
 const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -533,7 +578,7 @@ size_t vof_query_workspace(int n_i, int n_j, int B) {
     std::vector<std::pair<size_t, size_t>> lv{{ni, nj}};
     while (std::max(lv.back().first, lv.back().second) > (size_t)COARSEST_MAX)
         lv.push_back({(lv.back().first + 1) / 2, (lv.back().second + 1) / 2});
-    total += 8 * b * 3 * ni * nj;
+    total += 9 * b * 3 * ni * nj;
     for (size_t l = 0; l < lv.size(); ++l) {
         size_t npts = lv[l].first * lv[l].second;
         if (l + 1 < lv.size()) total += 2 * b * 3 * npts;
@@ -605,15 +650,16 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     int nl = (int)c->L.size();
     if (nl > 16) { c->err = "too many levels"; return -1; }
     size_t len0 = 3 * l0.npts;
-    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky})
+    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky, &c->b32})
         if (int rc = dev_alloc(c, v, (size_t)B * len0)) return rc;
     for (int l = 0; l < nl; ++l) {
         Level& lv = c->L[l];
-        if (l + 1 < nl) if (int rc = dev_alloc(c, &lv.r, (size_t)B * 3 * lv.npts)) return rc;
-        if (l + 1 < nl) if (int rc = dev_alloc(c, &lv.x2, (size_t)B * 3 * lv.npts)) return rc;
+        auto valloc = [&](void** q) { double* t = nullptr; int rc = dev_alloc(c, &t, (size_t)B * 3 * lv.npts); *q = t; return rc; };
+        if (l + 1 < nl) if (int rc = valloc(&lv.r)) return rc;
+        if (l + 1 < nl) if (int rc = valloc(&lv.x2)) return rc;
         if (l > 0) {
-            if (int rc = dev_alloc(c, &lv.x, (size_t)B * 3 * lv.npts)) return rc;
-            if (int rc = dev_alloc(c, &lv.b, (size_t)B * 3 * lv.npts)) return rc;
+            if (int rc = valloc(&lv.x)) return rc;
+            if (int rc = valloc(&lv.b)) return rc;
         }
         if (l > 0 || nl == 1) {
             double* C = nullptr;
@@ -717,11 +763,12 @@ int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof
         k_rhs<<<grid2d(f.ni, f.nj, n_pairs), blk2d, 0, c->stream>>>(movie, frame_stride(c), c->Nj, f.ni, f.nj, c->kb);
     }
     HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)n_pairs * 3 * f.npts * sizeof(double), c->stream));
-    if (c->fused) {
-        smooth_level(c, 0, c->kx, f.x2, c->kb, n_sweeps, true, false, n_pairs, nullptr);
+    if (c->vfloat) {
+        size_t n = (size_t)n_pairs * 3 * f.npts;
+        k_convert<double, float><<<1024, 256, 0, c->stream>>>(c->kb, (float*)c->b32, n);
+        smooth_level_t<float>(c, 0, (float*)c->ky, (float*)f.x2, (const float*)c->b32, n_sweeps, true, false, n_pairs, nullptr);
     } else {
-        for (int s = 0; s < n_sweeps; ++s)
-            for (int col = 0; col < 4; ++col) gs_colour(c, 0, c->kx, c->kb, col, n_pairs, nullptr);
+        smooth_level_t<double>(c, 0, c->kx, (double*)f.x2, c->kb, n_sweeps, true, false, n_pairs, nullptr);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -829,7 +876,28 @@ int vof_debug_level_shape(vof_ctx* c, int level, int* n_i, int* n_j) {
     size_t nbytes = (size_t)c->npairs * 3 * lv.npts * sizeof(double);                 \
     (void)nbytes;
 
-// scratch vectors for the debug API: reuse Krylov buffers (level-0 sized, always large enough)
+// The debug API moves host float64 arrays in and out of V-typed device buffers (kp, kv, kt; staging: krh).
+static int dbg_up(vof_ctx* c, void* dst_v, const double* host, size_t n) {
+    if (c->vfloat) {
+        HIPCHK(hipMemcpyAsync(c->krh, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        k_convert<double, float><<<256, 256, 0, c->stream>>>(c->krh, (float*)dst_v, n);
+    } else {
+        HIPCHK(hipMemcpyAsync(dst_v, host, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    return 0;
+}
+static int dbg_down(vof_ctx* c, double* host, const void* src_v, size_t n) {
+    if (c->vfloat) {
+        k_convert<float, double><<<256, 256, 0, c->stream>>>((const float*)src_v, c->krh, n);
+        HIPCHK(hipMemcpyAsync(host, c->krh, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(host, src_v, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int vof_debug_rhs(vof_ctx* c, double* b_host) {
     DBG_LEVEL(0)
     k_rhs<<<grid2d(lv.ni, lv.nj, c->npairs), blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->kb);
@@ -840,18 +908,23 @@ int vof_debug_rhs(vof_ctx* c, double* b_host) {
 
 int vof_debug_apply(vof_ctx* c, int level, const double* x_host, double* y_host) {
     DBG_LEVEL(level)
-    HIPCHK(hipMemcpyAsync(c->kp, x_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    apply_level(c, level, c->kp, nullptr, c->kv, 0, c->npairs, nullptr);
-    HIPCHK(hipMemcpyAsync(y_host, c->kv, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    size_t n = nbytes / sizeof(double);
+    if (int rc = dbg_up(c, c->kp, x_host, n)) return rc;
+    if (level == 0) {   // the Krylov product: V-typed x, FP64 result
+        krylov_apply(c, c->kp, c->kv, c->npairs, nullptr);
+        HIPCHK(hipMemcpyAsync(y_host, c->kv, nbytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    VDISPATCH(c, apply_level_t<VT>(c, level, (const VT*)c->kp, (const VT*)nullptr, (VT*)c->kv, 0, c->npairs, nullptr));
+    return dbg_down(c, y_host, c->kv, n);
 }
 
 int vof_debug_gs(vof_ctx* c, int level, double* x_host, const double* b_host, int colour) {
     DBG_LEVEL(level)
     if (colour < 0 || colour > 3) { c->err = "bad colour"; return -1; }
-    if (level == (int)c->L.size() - 1 && c->L.size() > 1 && false) { c->err = "coarsest level has no smoother"; return -1; }
+    if (c->vfloat) { c->err = "the per-colour reference smoother works on float64 vectors only"; return -1; }
     HIPCHK(hipMemcpyAsync(c->kp, x_host, nbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->kv, b_host, nbytes, hipMemcpyHostToDevice, c->stream));
     gs_colour(c, level, c->kp, c->kv, colour, c->npairs, nullptr);
@@ -864,18 +937,18 @@ int vof_debug_gs(vof_ctx* c, int level, double* x_host, const double* b_host, in
 int vof_debug_sweep(vof_ctx* c, int level, double* x_host, const double* b_host, int reverse, int from_zero) {
     DBG_LEVEL(level)
     if (level + 1 >= (int)c->L.size()) { c->err = "coarsest level has no smoother"; return -1; }
-    HIPCHK(hipMemcpyAsync(c->kp, x_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->kv, b_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    sweep_level(c, level, from_zero ? nullptr : c->kp, c->kt, c->kv, reverse != 0, c->npairs, nullptr);
-    HIPCHK(hipMemcpyAsync(x_host, c->kt, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    size_t n = nbytes / sizeof(double);
+    if (int rc = dbg_up(c, c->kp, x_host, n)) return rc;
+    if (int rc = dbg_up(c, c->kv, b_host, n)) return rc;
+    VDISPATCH(c, sweep_level_t<VT>(c, level, from_zero ? (const VT*)nullptr : (const VT*)c->kp, (VT*)c->kt,
+                                   (const VT*)c->kv, reverse != 0, c->npairs, nullptr));
+    return dbg_down(c, x_host, c->kt, n);
 }
 
 int vof_set_fused_sweeps(vof_ctx* c, int on) {
     if (!c) return -1;
     c->fused = on != 0;
+    if (!c->fused) c->vfloat = false;
     return 0;
 }
 
@@ -883,25 +956,19 @@ int vof_debug_restrict(vof_ctx* c, int level, const double* fine_host, double* c
     DBG_LEVEL(level)
     if (level + 1 >= (int)c->L.size()) { c->err = "no coarser level"; return -1; }
     Level& k = c->L[level + 1];
-    HIPCHK(hipMemcpyAsync(c->kp, fine_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    restrict_level(c, level, c->kp, c->kv, c->npairs, nullptr);
-    HIPCHK(hipMemcpyAsync(coarse_host, c->kv, (size_t)c->npairs * 3 * k.npts * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    if (int rc = dbg_up(c, c->kp, fine_host, nbytes / sizeof(double))) return rc;
+    VDISPATCH(c, restrict_level_t<VT>(c, level, (const VT*)c->kp, (VT*)c->kv, c->npairs, nullptr));
+    return dbg_down(c, coarse_host, c->kv, (size_t)c->npairs * 3 * k.npts);
 }
 
 int vof_debug_prolong_add(vof_ctx* c, int level, double* fine_host, const double* coarse_host) {
     DBG_LEVEL(level)
     if (level + 1 >= (int)c->L.size()) { c->err = "no coarser level"; return -1; }
     Level& k = c->L[level + 1];
-    HIPCHK(hipMemcpyAsync(c->kp, fine_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->kv, coarse_host, (size_t)c->npairs * 3 * k.npts * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    prolong_add_level(c, level, c->kp, c->kv, c->npairs, nullptr);
-    HIPCHK(hipMemcpyAsync(fine_host, c->kp, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    if (int rc = dbg_up(c, c->kp, fine_host, nbytes / sizeof(double))) return rc;
+    if (int rc = dbg_up(c, c->kv, coarse_host, (size_t)c->npairs * 3 * k.npts)) return rc;
+    VDISPATCH(c, prolong_add_level_t<VT>(c, level, (VT*)c->kp, (const VT*)c->kv, c->npairs, nullptr));
+    return dbg_down(c, fine_host, c->kp, nbytes / sizeof(double));
 }
 
 int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
@@ -929,23 +996,19 @@ int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
 
 int vof_debug_vcycle(vof_ctx* c, const double* r_host, double* e_host) {
     DBG_LEVEL(0)
-    HIPCHK(hipMemcpyAsync(c->kp, r_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    vcycle(c, 0, c->ky, c->kp, c->npairs, nullptr);
-    HIPCHK(hipMemcpyAsync(e_host, c->ky, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    size_t n = nbytes / sizeof(double);
+    if (int rc = dbg_up(c, c->kp, r_host, n)) return rc;
+    vcycle(c, c->ky, c->kp, c->npairs, nullptr);
+    return dbg_down(c, e_host, c->ky, n);
 }
 
 int vof_debug_coarse_solve(vof_ctx* c, const double* r_host, double* e_host) {
     int last = c ? (int)c->L.size() - 1 : 0;
     DBG_LEVEL(last)
-    HIPCHK(hipMemcpyAsync(c->kp, r_host, nbytes, hipMemcpyHostToDevice, c->stream));
-    coarse_solve(c, c->kp, c->kv, c->npairs, nullptr);
-    HIPCHK(hipMemcpyAsync(e_host, c->kv, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    return 0;
+    size_t n = nbytes / sizeof(double);
+    if (int rc = dbg_up(c, c->kp, r_host, n)) return rc;
+    VDISPATCH(c, coarse_solve_t<VT>(c, (const VT*)c->kp, (VT*)c->kv, c->npairs, nullptr));
+    return dbg_down(c, e_host, c->kv, n);
 }
 
 }  // extern "C"

@@ -138,7 +138,8 @@ struct Nbr {
     double u[9], w[9], g[9];  // index (di+1)*3 + (dj+1); g only at the 5-point positions
 };
 
-__device__ __forceinline__ void load_nbr(const double* __restrict__ x, size_t npts, int ni, int nj, int p, int q,
+template <typename XT>
+__device__ __forceinline__ void load_nbr(const XT* __restrict__ x, size_t npts, int ni, int nj, int p, int q,
                                          Nbr& n) {
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
@@ -153,9 +154,9 @@ __device__ __forceinline__ void load_nbr(const double* __restrict__ x, size_t np
             size_t idx = (size_t)fp * nj + fq;
             double s = (oi && oj) ? 2.0 : 1.0;
             int t = (di + 1) * 3 + (dj + 1);
-            n.u[t] = s * x[idx];
-            n.w[t] = s * x[npts + idx];
-            if (di == 0 || dj == 0) n.g[t] = s * x[2 * npts + idx];
+            n.u[t] = s * (double)x[idx];
+            n.w[t] = s * (double)x[npts + idx];
+            if (di == 0 || dj == 0) n.g[t] = s * (double)x[2 * npts + idx];
         }
     }
 }
@@ -198,11 +199,12 @@ __global__ __launch_bounds__(NT) void k_rhs(const double* __restrict__ frames, s
 // ------------------------------------------------------------------------------------------
 // k_apply0: y = A x (MODE 0) or y = b - A x (MODE 1) on the fine level, matrix-free.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+// XT / BT / YT: storage types of x, b, y (float for the mixed-precision V-cycle; arithmetic is always FP64).
+template <int MODE, typename XT, typename BT, typename YT>
 __global__ __launch_bounds__(NT) void k_apply0(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
                                                int nj, double alpha, double beta, int quirks,
-                                               const double* __restrict__ x, const double* __restrict__ b,
-                                               double* __restrict__ y, const int* __restrict__ active) {
+                                               const XT* __restrict__ x, const BT* __restrict__ b,
+                                               YT* __restrict__ y, const int* __restrict__ active) {
     int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (active && !active[pair]) return;
     if (p >= ni || q >= nj) return;
@@ -217,13 +219,13 @@ __global__ __launch_bounds__(NT) void k_apply0(const double* __restrict__ frames
     y1 += (P * (k.Dyy - 2 * P) - 4 * alpha) * n.w[4] + P * k.Dxy * n.u[4];
     y2 += (-1 - 4 * beta) * n.g[4] + k.Dx * n.u[4] + k.Dy * n.w[4];
     if (MODE == 1) {
-        y0 = b[off + idx] - y0;
-        y1 = b[off + npts + idx] - y1;
-        y2 = b[off + 2 * npts + idx] - y2;
+        y0 = (double)b[off + idx] - y0;
+        y1 = (double)b[off + npts + idx] - y1;
+        y2 = (double)b[off + 2 * npts + idx] - y2;
     }
-    y[off + idx] = y0;
-    y[off + npts + idx] = y1;
-    y[off + 2 * npts + idx] = y2;
+    y[off + idx] = (YT)y0;
+    y[off + npts + idx] = (YT)y1;
+    y[off + 2 * npts + idx] = (YT)y2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -261,8 +263,8 @@ __global__ __launch_bounds__(NT) void k_gs0(const double* __restrict__ frames, s
 // ------------------------------------------------------------------------------------------
 // Stored-stencil levels (Galerkin coarse operators): C[pair][(a*3+b)*9 + r*3+c][npts].
 // ------------------------------------------------------------------------------------------
-template <typename CT>
-__device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t npts, const double* __restrict__ x,
+template <typename CT, typename VT>
+__device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t npts, const VT* __restrict__ x,
                                                 int ni, int nj, int p, int q, double& y0, double& y1, double& y2,
                                                 bool include_diag) {
     const CLay L(ni, nj);
@@ -278,7 +280,7 @@ __device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t
             if (tq < 0 || tq >= nj) continue;
             if (!include_diag && a == 1 && bb == 1) continue;
             size_t t = (size_t)tp * nj + tq;
-            double xu = x[t], xw = x[npts + t], xg = x[2 * npts + t];
+            double xu = (double)x[t], xw = (double)x[npts + t], xg = (double)x[2 * npts + t];
             const CT* cb = C + (size_t)((a * 3 + bb) * 9) * cps + idx;
             y0 += (double)cb[0] * xu + (double)cb[cps] * xw + (double)cb[2 * cps] * xg;
             y1 += (double)cb[3 * cps] * xu + (double)cb[4 * cps] * xw + (double)cb[5 * cps] * xg;
@@ -287,24 +289,24 @@ __device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t
     }
 }
 
-template <typename CT, int MODE>
-__global__ __launch_bounds__(NT) void k_apply(const CT* __restrict__ C, int ni, int nj, const double* __restrict__ x,
-                                              const double* __restrict__ b, double* __restrict__ y,
+template <typename CT, int MODE, typename VT>
+__global__ __launch_bounds__(NT) void k_apply(const CT* __restrict__ C, int ni, int nj, const VT* __restrict__ x,
+                                              const VT* __restrict__ b, VT* __restrict__ y,
                                               const int* __restrict__ active) {
     int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (active && !active[pair]) return;
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
     double y0, y1, y2;
-    stencil_offdiag<CT>(C + (size_t)pair * 81 * CLay(ni, nj).plane, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
+    stencil_offdiag<CT, VT>(C + (size_t)pair * 81 * CLay(ni, nj).plane, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
     if (MODE == 1) {
-        y0 = b[off + idx] - y0;
-        y1 = b[off + npts + idx] - y1;
-        y2 = b[off + 2 * npts + idx] - y2;
+        y0 = (double)b[off + idx] - y0;
+        y1 = (double)b[off + npts + idx] - y1;
+        y2 = (double)b[off + 2 * npts + idx] - y2;
     }
-    y[off + idx] = y0;
-    y[off + npts + idx] = y1;
-    y[off + 2 * npts + idx] = y2;
+    y[off + idx] = (VT)y0;
+    y[off + npts + idx] = (VT)y1;
+    y[off + 2 * npts + idx] = (VT)y2;
 }
 
 __device__ __forceinline__ void solve3(const double* D, double r0, double r1, double r2, double& x0, double& x1,
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(NT) void k_gs(const CT* __restrict__ C, int ni, int
     const CLay L(ni, nj);
     const CT* Cp = C + (size_t)pair * 81 * L.plane;
     double y0, y1, y2;
-    stencil_offdiag<CT>(Cp, npts, x + off, ni, nj, p, q, y0, y1, y2, false);
+    stencil_offdiag<CT, double>(Cp, npts, x + off, ni, nj, p, q, y0, y1, y2, false);
     double D[9];
     const size_t cidx = L.idx(p, q);
 #pragma unroll
@@ -345,14 +347,15 @@ __global__ __launch_bounds__(NT) void k_gs(const CT* __restrict__ C, int ni, int
 // ------------------------------------------------------------------------------------------
 // Transfer operators.  Coarse point c sits on fine point 2c; R = P^T / 4.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_restrict(const double* __restrict__ fine, int nfi, int nfj,
-                                                 double* __restrict__ coarse, int nci, int ncj,
+template <typename VT>
+__global__ __launch_bounds__(NT) void k_restrict(const VT* __restrict__ fine, int nfi, int nfj,
+                                                 VT* __restrict__ coarse, int nci, int ncj,
                                                  const int* __restrict__ active) {
     int cq = blockIdx.x * BX + threadIdx.x, cp = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (active && !active[pair]) return;
     if (cp >= nci || cq >= ncj) return;
     size_t nf = (size_t)nfi * nfj, nc = (size_t)nci * ncj;
-    const double* f = fine + (size_t)pair * 3 * nf;
+    const VT* f = fine + (size_t)pair * 3 * nf;
     double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
@@ -365,26 +368,27 @@ __global__ __launch_bounds__(NT) void k_restrict(const double* __restrict__ fine
             if (fq < 0 || fq >= nfj) continue;
             double w = wi * pweight(fq, cq, ncj);
             size_t t = (size_t)fp * nfj + fq;
-            s0 += w * f[t];
-            s1 += w * f[nf + t];
-            s2 += w * f[2 * nf + t];
+            s0 += w * (double)f[t];
+            s1 += w * (double)f[nf + t];
+            s2 += w * (double)f[2 * nf + t];
         }
     }
     size_t idx = (size_t)cp * ncj + cq;
-    double* c = coarse + (size_t)pair * 3 * nc;
-    c[idx] = 0.25 * s0;
-    c[nc + idx] = 0.25 * s1;
-    c[2 * nc + idx] = 0.25 * s2;
+    VT* c = coarse + (size_t)pair * 3 * nc;
+    c[idx] = (VT)(0.25 * s0);
+    c[nc + idx] = (VT)(0.25 * s1);
+    c[2 * nc + idx] = (VT)(0.25 * s2);
 }
 
-__global__ __launch_bounds__(NT) void k_prolong_add(double* __restrict__ fine, int nfi, int nfj,
-                                                    const double* __restrict__ coarse, int nci, int ncj,
+template <typename VT>
+__global__ __launch_bounds__(NT) void k_prolong_add(VT* __restrict__ fine, int nfi, int nfj,
+                                                    const VT* __restrict__ coarse, int nci, int ncj,
                                                     const int* __restrict__ active) {
     int fq = blockIdx.x * BX + threadIdx.x, fp = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (active && !active[pair]) return;
     if (fp >= nfi || fq >= nfj) return;
     size_t nf = (size_t)nfi * nfj, nc = (size_t)nci * ncj;
-    const double* c = coarse + (size_t)pair * 3 * nc;
+    const VT* c = coarse + (size_t)pair * 3 * nc;
     int cp0 = fp >> 1, cq0 = fq >> 1;
     double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
@@ -400,16 +404,16 @@ __global__ __launch_bounds__(NT) void k_prolong_add(double* __restrict__ fine, i
             double w = wi * pweight(fq, cq, ncj);
             if (w == 0.0) continue;
             size_t t = (size_t)cp * ncj + cq;
-            s0 += w * c[t];
-            s1 += w * c[nc + t];
-            s2 += w * c[2 * nc + t];
+            s0 += w * (double)c[t];
+            s1 += w * (double)c[nc + t];
+            s2 += w * (double)c[2 * nc + t];
         }
     }
     size_t idx = (size_t)fp * nfj + fq;
-    double* f = fine + (size_t)pair * 3 * nf;
-    f[idx] += s0;
-    f[nf + idx] += s1;
-    f[2 * nf + idx] += s2;
+    VT* f = fine + (size_t)pair * 3 * nf;
+    f[idx] = (VT)((double)f[idx] + s0);
+    f[nf + idx] = (VT)((double)f[nf + idx] + s1);
+    f[2 * nf + idx] = (VT)((double)f[2 * nf + idx] + s2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -562,18 +566,19 @@ __global__ void k_coarse_invert(double* __restrict__ W, int nd, double* __restri
     }
 }
 
-__global__ void k_coarse_solve(const double* __restrict__ invT, int nd, const double* __restrict__ r,
-                               double* __restrict__ e, const int* __restrict__ active) {
+template <typename VT>
+__global__ void k_coarse_solve(const double* __restrict__ invT, int nd, const VT* __restrict__ r,
+                               VT* __restrict__ e, const int* __restrict__ active) {
     int pair = blockIdx.x;
     if (active && !active[pair]) return;
     extern __shared__ double s_r[];
-    for (int j = threadIdx.x; j < nd; j += blockDim.x) s_r[j] = r[(size_t)pair * nd + j];
+    for (int j = threadIdx.x; j < nd; j += blockDim.x) s_r[j] = (double)r[(size_t)pair * nd + j];
     __syncthreads();
     const double* M = invT + (size_t)pair * nd * nd;
     for (int i = threadIdx.x; i < nd; i += blockDim.x) {
         double s = 0.0;
         for (int j = 0; j < nd; ++j) s += M[(size_t)j * nd + i] * s_r[j];
-        e[(size_t)pair * nd + i] = s;
+        e[(size_t)pair * nd + i] = (VT)s;
     }
 }
 
@@ -624,40 +629,48 @@ __global__ __launch_bounds__(RBLK) void k_dot2(const double* __restrict__ a1, co
     block_store_partials(s0, s1, 0.0, partials, a2 ? 2 : 1, gridDim.x, pair, blockIdx.x);
 }
 
-// p = r + beta (p - omega v)
+// p = r + beta (p - omega v); optionally also a VT copy of p (the V-cycle's right-hand side)
+template <typename VT>
 __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const double* __restrict__ r,
                                                    const double* __restrict__ v, size_t len,
                                                    const PairScalars* __restrict__ sc,
-                                                   const int* __restrict__ active) {
+                                                   const int* __restrict__ active, VT* __restrict__ pcopy) {
     int pair = blockIdx.y;
     if (!active[pair]) return;
     double beta = sc[pair].beta, omega = sc[pair].omega;
     size_t off = (size_t)pair * len;
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK)
-        p[off + i] = r[off + i] + beta * (p[off + i] - omega * v[off + i]);
+    {
+        double t = r[off + i] + beta * (p[off + i] - omega * v[off + i]);
+        p[off + i] = t;
+        if (pcopy) pcopy[off + i] = (VT)t;
+    }
 }
 
-// x += alpha y ; r -= alpha v (r becomes s) ; partial (s, s)
-__global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ x, const double* __restrict__ y,
+// x += alpha y ; r -= alpha v (r becomes s) ; partial (s, s); optionally a VT copy of s
+template <typename VT>
+__global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ x, const VT* __restrict__ y,
                                                    double* __restrict__ r, const double* __restrict__ v, size_t len,
                                                    const PairScalars* __restrict__ sc, double* __restrict__ partials,
-                                                   const int* __restrict__ active) {
+                                                   const int* __restrict__ active, VT* __restrict__ scopy) {
     int pair = blockIdx.y;
     if (!active[pair]) return;
     double alpha = sc[pair].alpha;
     size_t off = (size_t)pair * len;
     double ss = 0;
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
-        x[off + i] += alpha * y[off + i];
+        x[off + i] += alpha * (double)y[off + i];
         double s = r[off + i] - alpha * v[off + i];
         r[off + i] = s;
+        if (scopy) scopy[off + i] = (VT)s;
         ss += s * s;
     }
     block_store_partials(ss, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
 }
 
 // x += omega z ; r = s - omega t ; partial (r, r)
-__global__ __launch_bounds__(RBLK) void k_update_xr(double* __restrict__ x, const double* __restrict__ z,
+template <typename VT>
+__global__ __launch_bounds__(RBLK) void k_update_xr(double* __restrict__ x, const VT* __restrict__ z,
                                                     double* __restrict__ r, const double* __restrict__ t, size_t len,
                                                     const PairScalars* __restrict__ sc, double* __restrict__ partials,
                                                     const int* __restrict__ active) {
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(RBLK) void k_update_xr(double* __restrict__ x, cons
     size_t off = (size_t)pair * len;
     double rr = 0;
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
-        x[off + i] += omega * z[off + i];
+        x[off + i] += omega * (double)z[off + i];
         double s = r[off + i] - omega * t[off + i];
         r[off + i] = s;
         rr += s * s;
@@ -680,6 +693,12 @@ __global__ void k_fill(double* __restrict__ x, size_t npts, double c0, double c1
     size_t len = 3 * npts, off = (size_t)pair * len;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
         x[off + i] = i < npts ? c0 : (i < 2 * npts ? c1 : c2);
+}
+
+template <typename TA, typename TB>
+__global__ void k_convert(const TA* __restrict__ a, TB* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        b[i] = (TB)a[i];
 }
 
 enum ScalarStep { S_BNORM = 0, S_R0, S_RHO, S_ALPHA, S_S, S_OMEGA, S_R, S_FINAL };
@@ -861,8 +880,8 @@ struct SweepFine {
     static constexpr bool kHasImage = true;
 
     // new values of point (p, q) at relative row rr / local column lc; xs = x ring, im = image ring
-    template <class G>
-    __device__ __forceinline__ void update(const SweepGeom& g, const double* xs, const double* im, int pair, int p,
+    template <class G, typename VT>
+    __device__ __forceinline__ void update(const SweepGeom& g, const VT* xs, const double* im, int pair, int p,
                                            int q, int rr, int lc, double b0, double b1, double b2, double& u,
                                            double& w, double& gm) const {
         // image neighbourhood (full-image rows p..p+2, cols q..q+2  <->  ring rows rr-1..rr+1, cols lc..lc+2)
@@ -887,7 +906,7 @@ struct SweepFine {
             int tp = p + di;
             bool oi = (tp < 0) || (tp >= g.ni);
             int fr = fold(tp, g.ni) - g.p0;
-            const double* row = xs + sw_slot(fr) * 3 * SW_W;
+            const VT* row = xs + sw_slot(fr) * 3 * SW_W;
 #pragma unroll
             for (int dj = -1; dj <= 1; ++dj) {
                 if (di == 0 && dj == 0) continue;
@@ -896,9 +915,9 @@ struct SweepFine {
                 int cc = sw_cs<G>(fold(tq, g.nj) - g.qs);
                 double s = (oi && oj) ? 2.0 : 1.0;
                 int t = (di + 1) * 3 + (dj + 1);
-                n.u[t] = s * row[cc];
-                n.w[t] = s * row[SW_W + cc];
-                if (di == 0 || dj == 0) n.g[t] = s * row[2 * SW_W + cc];
+                n.u[t] = s * (double)row[cc];
+                n.w[t] = s * (double)row[SW_W + cc];
+                if (di == 0 || dj == 0) n.g[t] = s * (double)row[2 * SW_W + cc];
             }
         }
         double y0, y1, y2;
@@ -913,14 +932,14 @@ struct SweepFine {
     }
 };
 
-template <class Pol, class G>
+template <class Pol, class G, typename VT>
 __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po,
-                                               const double* __restrict__ x_in, double* __restrict__ x_out,
-                                               const double* __restrict__ b, const int* __restrict__ active) {
+                                               const VT* __restrict__ x_in, VT* __restrict__ x_out,
+                                               const VT* __restrict__ b, const int* __restrict__ active) {
     constexpr int SW_W = G::W, SW_IW = G::IW, SW_OUT = G::OUT, SW_THREADS = G::THREADS;
     extern __shared__ double sw_lds[];
-    double* xs = sw_lds;                            // [SW_RING][3][SW_W]
-    double* im = sw_lds + SW_RING * 3 * SW_W;       // [SW_RING][SW_IW]   (only if Pol::kHasImage)
+    VT* xs = reinterpret_cast<VT*>(sw_lds);                                                  // [SW_RING][3][SW_W]
+    double* im = reinterpret_cast<double*>(reinterpret_cast<char*>(sw_lds) + SW_RING * 3 * SW_W * sizeof(VT));  // [SW_RING][SW_IW]
     const int pair = blockIdx.z;
     if (active && !active[pair]) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -931,9 +950,9 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     const int q0 = G::HALO_WAVE ? blockIdx.x * SW_OUT : blockIdx.x * SW_OUT - po;
     g.qs = q0 - SW_HALO;
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
-    const double* xin = x_in ? x_in + off : nullptr;
-    double* xout = x_out + off;
-    const double* bp = b + off;
+    const VT* xin = x_in ? x_in + off : nullptr;
+    VT* xout = x_out + off;
+    const VT* bp = b + off;
     const double* img = nullptr;
     if (Pol::kHasImage) img = pol.frames + (size_t)pair * pol.frame_stride;
 
@@ -989,7 +1008,8 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
                 xout[(size_t)m_f[k] * npts + (size_t)p * nj + qq] = xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs<G>(m_lc[k])];
         }
         // (2) global loads of relative rows e+2, e+3 into registers
-        double lx[3], li[2] = {0.0, 0.0};
+        VT lx[3];
+        double li[2] = {0.0, 0.0};
         constexpr int NIMG = 2 * (SW_W + 2);                       // image elements per step (2 rows)
         constexpr int KIMG = (NIMG + SW_THREADS - 1) / SW_THREADS;  // 1 (GeoB) or 2 (GeoA)
         const bool do_load = (e + 2 <= TI + 1);
@@ -997,7 +1017,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
         for (int k = 0; k < 3; ++k) {
             int rr = e + 2 + m_row[k];
             int p = g.p0 + rr, qq = g.qs + m_lc[k];
-            lx[k] = 0.0;
+            lx[k] = (VT)0;
             if (do_load && m_on[k] && xin && p >= 0 && p < ni && qq >= 0 && qq < nj)
                 lx[k] = xin[(size_t)m_f[k] * npts + (size_t)p * nj + qq];
         }
@@ -1020,7 +1040,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
             int pn = g.p0 + rrn;
             if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni) {
                 size_t t = (size_t)pn * nj + q;
-                bn0 = bp[t]; bn1 = bp[npts + t]; bn2 = bp[2 * npts + t];
+                bn0 = (double)bp[t]; bn1 = (double)bp[npts + t]; bn2 = (double)bp[2 * npts + t];
             }
         }
         // (4) the stage of this wave
@@ -1029,9 +1049,9 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
             int p = g.p0 + rr;
             if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
                 double u, w, gm;
-                pol.template update<G>(g, xs, im, pair, p, q, rr, lc, b0, b1, b2, u, w, gm);
-                double* row = xs + sw_slot(rr) * 3 * SW_W + sw_cs<G>(lc);
-                row[0] = u; row[SW_W] = w; row[2 * SW_W] = gm;
+                pol.template update<G, VT>(g, xs, im, pair, p, q, rr, lc, b0, b1, b2, u, w, gm);
+                VT* row = xs + sw_slot(rr) * 3 * SW_W + sw_cs<G>(lc);
+                row[0] = (VT)u; row[SW_W] = (VT)w; row[2 * SW_W] = (VT)gm;
             }
         }
         // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
@@ -1066,8 +1086,8 @@ struct SweepStored {
     size_t frame_stride = 0;
     int Nj = 0;
 
-    template <class G>
-    __device__ __forceinline__ void update(const SweepGeom& g, const double* xs, const double* /*im*/, int pair,
+    template <class G, typename VT>
+    __device__ __forceinline__ void update(const SweepGeom& g, const VT* xs, const double* /*im*/, int pair,
                                            int p, int q, int rr, int lc, double b0, double b1, double b2, double& u,
                                            double& w, double& gm) const {
         constexpr int SW_W = G::W;
@@ -1077,12 +1097,12 @@ struct SweepStored {
         double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double* row = xs + sw_slot(rr + a - 1) * 3 * SW_W;
+            const VT* row = xs + sw_slot(rr + a - 1) * 3 * SW_W;
 #pragma unroll
             for (int bb = 0; bb < 3; ++bb) {
                 if (a == 1 && bb == 1) continue;
                 int cc = sw_cs<G>(lc + bb - 1);
-                double xu = row[cc], xw = row[SW_W + cc], xg = row[2 * SW_W + cc];
+                double xu = (double)row[cc], xw = (double)row[SW_W + cc], xg = (double)row[2 * SW_W + cc];
                 const CT* cb = cp + (size_t)((a * 3 + bb) * 9) * npts;
                 y0 += (double)cb[0] * xu + (double)cb[npts] * xw + (double)cb[2 * npts] * xg;
                 y1 += (double)cb[3 * npts] * xu + (double)cb[4 * npts] * xw + (double)cb[5 * npts] * xg;

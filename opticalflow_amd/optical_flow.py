@@ -86,6 +86,7 @@ def variational_optical_flow(movie,
                              device=0,
                              max_pairs_in_flight=None,
                              coarse_precision="float32",
+                             vcycle_precision="float64",
                              verbose=False,
                              return_stats=False):
     """Variational optical flow with remodelling on an image stack, on one MI355X.
@@ -105,7 +106,9 @@ def variational_optical_flow(movie,
         to rtol=1e-11" on the GPU;
       * keyword-only extras: ``rtol`` (default 1e-6 = OF.py:1120), ``max_iterations`` (1000),
         ``reference_quirks`` (True keeps OF.py:698-699 'dy'=='dx' and the OF.py:1205
-        ``speed_functional`` assignment), ``device``, ``max_pairs_in_flight``, ``coarse_precision``,
+        ``speed_functional`` assignment), ``device``, ``max_pairs_in_flight``, ``coarse_precision`` /
+        ``vcycle_precision`` (storage precision inside the multigrid preconditioner only; the Krylov
+        iteration, the stopping rule and the result are float64 either way),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals).
     """
@@ -126,7 +129,8 @@ def variational_optical_flow(movie,
         delta_t=float(delta_t), initial_v_x=float(initial_v_x), initial_v_y=float(initial_v_y),
         initial_remodelling=float(initial_remodelling), rtol=float(rtol), max_iterations=int(max_iterations),
         reference_quirks=int(bool(reference_quirks)),
-        coarse_precision={"float64": 0, "float32": 1}[coarse_precision])
+        coarse_precision={"float64": 0, "float32": 1}[coarse_precision],
+        vcycle_precision={"float64": 0, "float32": 1}[vcycle_precision])
     if max_pairs_in_flight is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()

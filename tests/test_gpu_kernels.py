@@ -206,3 +206,51 @@ def test_vcycle_fused_equals_per_colour(native):
         s.set_fused_sweeps(False)
         e0 = s.debug_vcycle(r)
         assert relerr(e1, e0) < 1e-12
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", SWEEP_CASES[1:4])
+def test_float32_vcycle_vectors_building_blocks(native, kind, shape, npairs, alpha, beta, seed):
+    """vcycle_precision=1: V-cycle vectors stored as float32, arithmetic FP64 -> float32-rounding agreement."""
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, vcycle_precision=1, coarse_precision=1)
+    rng = np.random.default_rng(seed)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        b = s.debug_rhs()
+        x = rng.standard_normal(b.shape)
+        # Krylov product: float32 input vector, FP64 operator and result
+        y = s.debug_apply(0, x)
+        x32 = x.astype(np.float32).astype(np.float64)
+        for k in range(npairs):
+            assert relerr(y[k], orc.apply_operator_interior(mv[k], x32[k], alpha, beta)) < 1e-13
+        C = [mg.fine_stencil(mv[k], alpha, beta) for k in range(npairs)]
+        for reverse in (False, True):
+            xg = s.debug_sweep(0, x, b, reverse=reverse)
+            xr = x.copy()
+            for k in range(npairs):
+                mg.smooth(C[k], xr[k], b[k], 1, reverse=reverse)
+            assert relerr(xg, xr) < 5e-6
+        H = [mg.Hierarchy(mv[k], alpha, beta) for k in range(npairs)]
+        for lvl in range(s.num_levels - 1):
+            f = rng.standard_normal((npairs, 3) + s.level_shape(lvl))
+            cg = s.debug_restrict(lvl, f)
+            for k in range(npairs):
+                assert relerr(cg[k], mg.restrict(f[k])) < 1e-6
+            e = rng.standard_normal(cg.shape)
+            fg = s.debug_prolong_add(lvl, f, e)
+            for k in range(npairs):
+                assert relerr(fg[k], f[k] + mg.prolong(e[k], *f.shape[-2:])) < 1e-6
+            if lvl >= 1:
+                xs = rng.standard_normal(f.shape)
+                bs = rng.standard_normal(f.shape)
+                xg = s.debug_sweep(lvl, xs, bs)
+                xr = xs.copy()
+                for k in range(npairs):
+                    mg.smooth(H[k].levels[lvl], xr[k], bs[k], 1)
+                assert relerr(xg, xr) < 1e-4
+        r = s.debug_rhs()
+        e = s.debug_vcycle(r)
+        for k in range(npairs):
+            assert relerr(e[k], H[k].vcycle(r[k], 2, 2)) < 1e-3
+        with pytest.raises(native.VofError, match="float64"):
+            s.debug_gs(0, x, b, 0)

@@ -207,3 +207,15 @@ def test_medium_size_properties_512(of):
     xi = np.stack([res["v_x"][0], res["v_y"][0], res["remodelling"][0]])[:, 1:-1, 1:-1]
     r = orc.rhs_interior(movie[0], movie[1]) - orc.apply_operator_interior(movie[0], xi, 1.0, 1e4)
     assert np.linalg.norm(r) / np.linalg.norm(orc.rhs_interior(movie[0], movie[1])) <= 1.5e-6
+
+
+@pytest.mark.parametrize("name", ["g1_avof_simple_50.npz", "g3_stack_32x48x4.npz", "g7_texture_64x3.npz", "g6_8bit_64.npz"])
+def test_float32_vcycle_storage_same_answer(of, name):
+    """Mixed precision: float32 storage inside the preconditioner, FP64 Krylov iteration and stopping rule.
+    The converged answer must still match the reference's exact solution to the tight tolerance."""
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    res = of.variational_optical_flow(g["movie"], rtol=1e-10, vcycle_precision="float32", return_stats=True, **kw)
+    assert res["stats"]["converged"].all()
+    assert res["stats"]["relative_residual"].max() < 1e-9
+    check_fields(res, g, 1e-6 if "8bit" in name else TIGHT)
