@@ -294,11 +294,11 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
         if (c->hierarchy_float && l > 0) {
-            SweepStored<float> pol; pol.C = (const float*)lv.C;
+            SweepStored<float> pol; pol.C = (const float*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
             if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
             else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
         } else {
-            SweepStored<double> pol; pol.C = (const double*)lv.C;
+            SweepStored<double> pol; pol.C = (const double*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
             if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
             else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
         }

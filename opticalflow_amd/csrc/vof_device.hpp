@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace vof {
 
@@ -870,6 +871,24 @@ struct SweepGeom {
     int TI;
 };
 
+// Per-lane constants of a stage point (computed once, outside the row loop): LDS column slots of the three
+// neighbour columns (folded at the grid edge for the matrix-free level, plain for the stored levels).
+struct SweepCols {
+    int cL, cC, cR;   // x-ring column slots of q-1, q, q+1 with ghost folding
+    bool oL, oR;      // q-1 / q+1 is a ghost column
+    int uL, uR;       // x-ring column slots of q-1, q+1 without folding (stored levels)
+    int iL, iC, iR;   // image-ring column slots of full-image columns q, q+1, q+2
+    size_t cq;        // stored levels: column part of the colour-split coefficient index
+};
+// Per-row quantities of a stage (wave-uniform for the colour waves): ring offsets of rows p-1, p, p+1.
+struct SweepRows {
+    int xU, xC, xD;   // x-ring element offsets (slot * 3 * W) of the folded rows
+    bool oU, oD;      // p-1 / p+1 is a ghost row
+    int pU, pC, pD;   // x-ring element offsets of the unfolded rows (stored levels)
+    int iU, iC, iD;   // image-ring element offsets (slot * IW)
+    size_t cp;        // stored levels: row part of the colour-split coefficient index
+};
+
 // ---- policy: level 0, matrix-free -----------------------------------------------------------
 struct SweepFine {
     const double* frames;  // previous frame of pair 0
@@ -879,20 +898,17 @@ struct SweepFine {
     int quirks;
     static constexpr bool kHasImage = true;
 
-    // new values of point (p, q) at relative row rr / local column lc; xs = x ring, im = image ring
     template <class G, typename VT>
-    __device__ __forceinline__ void update(const SweepGeom& g, const VT* xs, const double* im, int pair, int p,
-                                           int q, int rr, int lc, double b0, double b1, double b2, double& u,
-                                           double& w, double& gm) const {
-        // image neighbourhood (full-image rows p..p+2, cols q..q+2  <->  ring rows rr-1..rr+1, cols lc..lc+2)
-        constexpr int SW_W = G::W, SW_IW = G::IW;
-        const double* r0 = im + sw_slot(rr - 1) * SW_IW;
-        const double* r1 = im + sw_slot(rr) * SW_IW;
-        const double* r2 = im + sw_slot(rr + 1) * SW_IW;
-        int c0 = sw_ci<G>(lc), c1 = sw_ci<G>(lc + 1), c2 = sw_ci<G>(lc + 2);
-        double imm = r0[c0], im0 = r0[c1], imp = r0[c2];
-        double i0m = r1[c0], i00 = r1[c1], i0p = r1[c2];
-        double ipm = r2[c0], ip0 = r2[c1], ipp = r2[c2];
+    __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs, const double* im,
+                                           int /*pair*/, double b0, double b1, double b2, double& u, double& w,
+                                           double& gm) const {
+        constexpr int W = G::W;
+        const double* r0 = im + rw.iU;
+        const double* r1 = im + rw.iC;
+        const double* r2 = im + rw.iD;
+        double imm = r0[cc.iL], im0 = r0[cc.iC], imp = r0[cc.iR];
+        double i0m = r1[cc.iL], i00 = r1[cc.iC], i0p = r1[cc.iR];
+        double ipm = r2[cc.iL], ip0 = r2[cc.iC], ipp = r2[cc.iR];
         PixCoef k;
         k.P = i00;
         k.Dx = (ip0 - im0) / 2;
@@ -900,26 +916,21 @@ struct SweepFine {
         k.Dxx = ip0 + im0 - 2 * i00;
         k.Dyy = i0p + i0m - 2 * i00;
         k.Dxy = (ipp - ipm - imp + imm) / 4;
+        const VT* ru = xs + rw.xU;
+        const VT* rc = xs + rw.xC;
+        const VT* rd = xs + rw.xD;
+        // corner ghosts carry the factor 2 (x(0,0) = x(2,0) + x(0,2) = 2 x(2,2))
+        const double sUL = (rw.oU && cc.oL) ? 2.0 : 1.0, sUR = (rw.oU && cc.oR) ? 2.0 : 1.0;
+        const double sDL = (rw.oD && cc.oL) ? 2.0 : 1.0, sDR = (rw.oD && cc.oR) ? 2.0 : 1.0;
         Nbr n;
-#pragma unroll
-        for (int di = -1; di <= 1; ++di) {
-            int tp = p + di;
-            bool oi = (tp < 0) || (tp >= g.ni);
-            int fr = fold(tp, g.ni) - g.p0;
-            const VT* row = xs + sw_slot(fr) * 3 * SW_W;
-#pragma unroll
-            for (int dj = -1; dj <= 1; ++dj) {
-                if (di == 0 && dj == 0) continue;
-                int tq = q + dj;
-                bool oj = (tq < 0) || (tq >= g.nj);
-                int cc = sw_cs<G>(fold(tq, g.nj) - g.qs);
-                double s = (oi && oj) ? 2.0 : 1.0;
-                int t = (di + 1) * 3 + (dj + 1);
-                n.u[t] = s * (double)row[cc];
-                n.w[t] = s * (double)row[SW_W + cc];
-                if (di == 0 || dj == 0) n.g[t] = s * (double)row[2 * SW_W + cc];
-            }
-        }
+        n.u[0] = sUL * (double)ru[cc.cL]; n.w[0] = sUL * (double)ru[W + cc.cL];
+        n.u[1] = (double)ru[cc.cC];       n.w[1] = (double)ru[W + cc.cC];       n.g[1] = (double)ru[2 * W + cc.cC];
+        n.u[2] = sUR * (double)ru[cc.cR]; n.w[2] = sUR * (double)ru[W + cc.cR];
+        n.u[3] = (double)rc[cc.cL];       n.w[3] = (double)rc[W + cc.cL];       n.g[3] = (double)rc[2 * W + cc.cL];
+        n.u[5] = (double)rc[cc.cR];       n.w[5] = (double)rc[W + cc.cR];       n.g[5] = (double)rc[2 * W + cc.cR];
+        n.u[6] = sDL * (double)rd[cc.cL]; n.w[6] = sDL * (double)rd[W + cc.cL];
+        n.u[7] = (double)rd[cc.cC];       n.w[7] = (double)rd[W + cc.cC];       n.g[7] = (double)rd[2 * W + cc.cC];
+        n.u[8] = sDR * (double)rd[cc.cR]; n.w[8] = sDR * (double)rd[W + cc.cR];
         double y0, y1, y2;
         offdiag0(k, alpha, beta, n, y0, y1, y2);
         const double P = k.P;
@@ -932,154 +943,11 @@ struct SweepFine {
     }
 };
 
-template <class Pol, class G, typename VT>
-__global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po,
-                                               const VT* __restrict__ x_in, VT* __restrict__ x_out,
-                                               const VT* __restrict__ b, const int* __restrict__ active) {
-    constexpr int SW_W = G::W, SW_IW = G::IW, SW_OUT = G::OUT, SW_THREADS = G::THREADS;
-    extern __shared__ double sw_lds[];
-    VT* xs = reinterpret_cast<VT*>(sw_lds);                                                  // [SW_RING][3][SW_W]
-    double* im = reinterpret_cast<double*>(reinterpret_cast<char*>(sw_lds) + SW_RING * 3 * SW_W * sizeof(VT));  // [SW_RING][SW_IW]
-    const int pair = blockIdx.z;
-    if (active && !active[pair]) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    SweepGeom g;
-    g.ni = ni; g.nj = nj; g.TI = TI;
-    g.p0 = blockIdx.y * TI - po;
-    // GeoB: strips always 128-aligned, po only swaps the column parity of the stages.  GeoA: strip origin shifted by po.
-    const int q0 = G::HALO_WAVE ? blockIdx.x * SW_OUT : blockIdx.x * SW_OUT - po;
-    g.qs = q0 - SW_HALO;
-    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
-    const VT* xin = x_in ? x_in + off : nullptr;
-    VT* xout = x_out + off;
-    const VT* bp = b + off;
-    const double* img = nullptr;
-    if (Pol::kHasImage) img = pol.frames + (size_t)pair * pol.frame_stride;
-
-    // stage of this lane: waves 0-3 own colour = wave on the 128 owned columns; wave 4 recomputes the six halo
-    // points (colour 0 at local columns 2, 132, 134; colour 1 at 3, 133; colour 2 at 132) that the owned columns
-    // of the later colours depend on.
-    int stage = wave, lc;
-    bool lane_on = true;
-    if (G::HALO_WAVE) {
-        // column parity of stage c is (c & 1) ^ po; for po = 1 the halo pattern is the mirror image
-        lc = SW_HALO + 2 * lane + ((wave & 1) ^ po);
-        if (wave == 4) {
-            const int hs[6] = {0, 0, 0, 1, 1, 2};
-            const int hl[6] = {2, SW_HALO + SW_OUT, SW_HALO + SW_OUT + 2, 3, SW_HALO + SW_OUT + 1, SW_HALO + SW_OUT};
-            lane_on = lane < 6;
-            stage = hs[lane_on ? lane : 0];
-            lc = hl[lane_on ? lane : 0];
-            if (po) lc = SW_W - 1 - lc;
-        }
-    } else {
-        // every colour wave covers its whole parity class of the strip; valid ranges 2..126, 3..125, 4..124, 5..123
-        lc = 2 * lane + (wave & 1);
-        lane_on = (lc >= 2 + wave) && (lc <= SW_W - 2 - wave);
-    }
-    const int stage_row_off = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
-    const int q = g.qs + lc;
-    const bool col_ok = lane_on && (q >= 0) && (q < nj);
-    const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
-
-    // element mapping of the cooperative load-in / write-out: 2 rows x 3 fields x SW_W columns
-    int m_row[3], m_f[3], m_lc[3];
-    bool m_on[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int idx = tid + SW_THREADS * k;
-        m_on[k] = idx < 2 * 3 * SW_W;
-        idx = m_on[k] ? idx : 0;
-        m_row[k] = idx / (3 * SW_W);
-        m_f[k] = (idx % (3 * SW_W)) / SW_W;
-        m_lc[k] = idx % SW_W;
-    }
-    double bn0 = 0, bn1 = 0, bn2 = 0;  // b of the stage's point for the NEXT step (prefetched)
-    const int s_end = TI / 2 + 4;
-    for (int s = -2; s <= s_end; ++s) {
-        const int e = 2 * s;
-        // (1) write-out of the rows that became final: relative rows e-10, e-9
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            int rr = e - 10 + m_row[k];
-            int p = g.p0 + rr, qq = g.qs + m_lc[k];
-            if (m_on[k] && rr >= 0 && rr < TI && p >= 0 && p < ni && m_lc[k] >= SW_HALO &&
-                m_lc[k] < SW_HALO + SW_OUT && qq >= 0 && qq < nj)
-                xout[(size_t)m_f[k] * npts + (size_t)p * nj + qq] = xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs<G>(m_lc[k])];
-        }
-        // (2) global loads of relative rows e+2, e+3 into registers
-        VT lx[3];
-        double li[2] = {0.0, 0.0};
-        constexpr int NIMG = 2 * (SW_W + 2);                       // image elements per step (2 rows)
-        constexpr int KIMG = (NIMG + SW_THREADS - 1) / SW_THREADS;  // 1 (GeoB) or 2 (GeoA)
-        const bool do_load = (e + 2 <= TI + 1);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            int rr = e + 2 + m_row[k];
-            int p = g.p0 + rr, qq = g.qs + m_lc[k];
-            lx[k] = (VT)0;
-            if (do_load && m_on[k] && xin && p >= 0 && p < ni && qq >= 0 && qq < nj)
-                lx[k] = xin[(size_t)m_f[k] * npts + (size_t)p * nj + qq];
-        }
-        if (Pol::kHasImage) {
-#pragma unroll
-            for (int k = 0; k < KIMG; ++k) {
-                int idx = tid + SW_THREADS * k;
-                if (idx < NIMG) {
-                    int rr = e + 2 + idx / (SW_W + 2), lci = idx % (SW_W + 2);
-                    int fr = g.p0 + rr + 1, fc = g.qs + lci;      // full-image row / column
-                    if (do_load && fr >= 0 && fr <= ni + 1 && fc >= 0 && fc <= nj + 1)
-                        li[k] = img[(size_t)fr * pol.Nj + fc];
-                }
-            }
-        }
-        // (3) this step's b (prefetched during the previous step) and the prefetch for the next step
-        double b0 = bn0, b1 = bn1, b2 = bn2;
-        {
-            int rrn = e + 2 + stage_row_off;
-            int pn = g.p0 + rrn;
-            if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni) {
-                size_t t = (size_t)pn * nj + q;
-                bn0 = (double)bp[t]; bn1 = (double)bp[npts + t]; bn2 = (double)bp[2 * npts + t];
-            }
-        }
-        // (4) the stage of this wave
-        {
-            int rr = e + stage_row_off;
-            int p = g.p0 + rr;
-            if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
-                double u, w, gm;
-                pol.template update<G, VT>(g, xs, im, pair, p, q, rr, lc, b0, b1, b2, u, w, gm);
-                VT* row = xs + sw_slot(rr) * 3 * SW_W + sw_cs<G>(lc);
-                row[0] = (VT)u; row[SW_W] = (VT)w; row[2 * SW_W] = (VT)gm;
-            }
-        }
-        // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
-        if (do_load) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int rr = e + 2 + m_row[k];
-                if (m_on[k]) xs[(sw_slot(rr) * 3 + m_f[k]) * SW_W + sw_cs<G>(m_lc[k])] = lx[k];
-            }
-            if (Pol::kHasImage) {
-#pragma unroll
-                for (int k = 0; k < KIMG; ++k) {
-                    int idx = tid + SW_THREADS * k;
-                    if (idx < NIMG) {
-                        int rr = e + 2 + idx / (SW_W + 2), lci = idx % (SW_W + 2);
-                        im[sw_slot(rr) * SW_IW + sw_ci<G>(lci)] = li[k];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ---- policy: stored Galerkin stencil (levels >= 1) -------------------------------------------
 template <typename CT>
 struct SweepStored {
     const CT* C;  // [pair][81][colour-split plane]
+    size_t plane; // CLay(ni, nj).plane
     static constexpr bool kHasImage = false;
     // dummies so the kernel template compiles for both policies
     const double* frames = nullptr;
@@ -1087,33 +955,233 @@ struct SweepStored {
     int Nj = 0;
 
     template <class G, typename VT>
-    __device__ __forceinline__ void update(const SweepGeom& g, const VT* xs, const double* /*im*/, int pair,
-                                           int p, int q, int rr, int lc, double b0, double b1, double b2, double& u,
+    __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs,
+                                           const double* /*im*/, int pair, double b0, double b1, double b2, double& u,
                                            double& w, double& gm) const {
-        constexpr int SW_W = G::W;
-        const CLay L(g.ni, g.nj);
-        const size_t npts = L.plane;
-        const CT* cp = C + (size_t)pair * 81 * npts + L.idx(p, q);
+        constexpr int W = G::W;
+        const CT* sp = C + (size_t)pair * 81 * plane + rw.cp;
+        const size_t cq = cc.cq;
+        const int rowo[3] = {rw.pU, rw.pC, rw.pD};
+        const int colo[3] = {cc.uL, cc.cC, cc.uR};
         double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const VT* row = xs + sw_slot(rr + a - 1) * 3 * SW_W;
+            const VT* row = xs + rowo[a];
 #pragma unroll
             for (int bb = 0; bb < 3; ++bb) {
                 if (a == 1 && bb == 1) continue;
-                int cc = sw_cs<G>(lc + bb - 1);
-                double xu = (double)row[cc], xw = (double)row[SW_W + cc], xg = (double)row[2 * SW_W + cc];
-                const CT* cb = cp + (size_t)((a * 3 + bb) * 9) * npts;
-                y0 += (double)cb[0] * xu + (double)cb[npts] * xw + (double)cb[2 * npts] * xg;
-                y1 += (double)cb[3 * npts] * xu + (double)cb[4 * npts] * xw + (double)cb[5 * npts] * xg;
-                y2 += (double)cb[6 * npts] * xu + (double)cb[7 * npts] * xw + (double)cb[8 * npts] * xg;
+                double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
+                const CT* cb = sp + (size_t)((a * 3 + bb) * 9) * plane;
+                y0 += (double)cb[cq] * xu + (double)(cb + plane)[cq] * xw + (double)(cb + 2 * plane)[cq] * xg;
+                y1 += (double)(cb + 3 * plane)[cq] * xu + (double)(cb + 4 * plane)[cq] * xw + (double)(cb + 5 * plane)[cq] * xg;
+                y2 += (double)(cb + 6 * plane)[cq] * xu + (double)(cb + 7 * plane)[cq] * xw + (double)(cb + 8 * plane)[cq] * xg;
             }
         }
         double D[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) D[t] = (double)cp[(size_t)(36 + t) * npts];
+        for (int t = 0; t < 9; ++t) D[t] = (double)(sp + (size_t)(36 + t) * plane)[cq];
         solve3(D, b0 - y0, b1 - y1, b2 - y2, u, w, gm);
     }
 };
+
+template <class G>
+__device__ __forceinline__ SweepRows sweep_rows(const SweepGeom& g, int rr, size_t hj, size_t sub) {
+    constexpr int W = G::W, IW = G::IW;
+    SweepRows r;
+    const int p = g.p0 + rr;
+    r.oU = p - 1 < 0;
+    r.oD = p + 1 >= g.ni;
+    const int sU = sw_slot(rr - 1), sC = sw_slot(rr), sD = sw_slot(rr + 1);
+    r.pU = sU * 3 * W; r.pC = sC * 3 * W; r.pD = sD * 3 * W;
+    r.xC = r.pC;
+    r.xU = r.oU ? r.pD : r.pU;     // ghost row -1 mirrors row 1, ghost row n mirrors row n-2
+    r.xD = r.oD ? r.pU : r.pD;
+    r.iU = sU * IW; r.iC = sC * IW; r.iD = sD * IW;
+    r.cp = (size_t)((p & 1) << 1) * sub + (size_t)(p >> 1) * hj;
+    return r;
+}
+
+template <class Pol, class G, typename VT>
+__global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po,
+                                               const VT* __restrict__ x_in, VT* __restrict__ x_out,
+                                               const VT* __restrict__ b, const int* __restrict__ active) {
+    constexpr int W = G::W, IW = G::IW, OUT = G::OUT, THREADS = G::THREADS;
+    extern __shared__ double sw_lds[];
+    VT* xs = reinterpret_cast<VT*>(sw_lds);                                                     // [SW_RING][3][W]
+    double* im = reinterpret_cast<double*>(reinterpret_cast<char*>(sw_lds) + SW_RING * 3 * W * sizeof(VT));  // [SW_RING][IW]
+    const int pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the stage's row arithmetic scalar
+    SweepGeom g;
+    g.ni = ni; g.nj = nj; g.TI = TI;
+    g.p0 = blockIdx.y * TI - po;
+    // GeoB: strips always 128-aligned, po only swaps the column parity of the stages.  GeoA: strip origin shifted by po.
+    const int q0 = G::HALO_WAVE ? blockIdx.x * OUT : blockIdx.x * OUT - po;
+    g.qs = q0 - SW_HALO;
+    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const VT* xin = x_in ? x_in + off : nullptr;
+    VT* xout = x_out + off;
+    const VT* bp = b + off;
+    const double* img = nullptr;
+    if (Pol::kHasImage) img = pol.frames + (size_t)pair * pol.frame_stride;
+    const CLay L(ni, nj);
+
+    // ---- stage of this lane.  Waves 0-3: colour = wave.  GeoB: wave 4 recomputes the six halo points.
+    int stage = wave, lc;
+    bool lane_on = true;
+    if (G::HALO_WAVE) {
+        // column parity of stage c is (c & 1) ^ po; for po = 1 the halo pattern is the mirror image
+        lc = SW_HALO + 2 * lane + ((wave & 1) ^ po);
+        if (wave == 4) {
+            const int hs[6] = {0, 0, 0, 1, 1, 2};
+            const int hl[6] = {2, SW_HALO + OUT, SW_HALO + OUT + 2, 3, SW_HALO + OUT + 1, SW_HALO + OUT};
+            lane_on = lane < 6;
+            stage = hs[lane_on ? lane : 0];
+            lc = hl[lane_on ? lane : 0];
+            if (po) lc = W - 1 - lc;
+        }
+    } else {
+        // every colour wave covers its whole parity class of the strip; valid ranges 2..126, 3..125, 4..124, 5..123
+        lc = 2 * lane + (wave & 1);
+        lane_on = (lc >= 2 + wave) && (lc <= W - 2 - wave);
+    }
+    const int q = g.qs + lc;
+    const bool col_ok = lane_on && (q >= 0) && (q < nj);
+    SweepCols cc;
+    {
+        const int qc = col_ok ? q : 0;      // keep the index math of masked lanes in range
+        const int lcc = col_ok ? lc : 2;
+        cc.oL = qc - 1 < 0;
+        cc.oR = qc + 1 >= nj;
+        cc.cC = sw_cs<G>(lcc);
+        cc.uL = sw_cs<G>(lcc - 1);
+        cc.uR = sw_cs<G>(lcc + 1);
+        cc.cL = cc.oL ? cc.uR : cc.uL;      // ghost column -1 mirrors column 1, ghost column n mirrors n-2
+        cc.cR = cc.oR ? cc.uL : cc.uR;
+        cc.iL = sw_ci<G>(lcc); cc.iC = sw_ci<G>(lcc + 1); cc.iR = sw_ci<G>(lcc + 2);
+        cc.cq = (size_t)(qc & 1) * L.sub + (size_t)(qc >> 1);
+    }
+    const size_t bcol = col_ok ? (size_t)q : 0;
+
+    // ---- element mapping of the cooperative load-in / write-out: 2 rows x 3 fields x W columns
+    int m_lds[3], m_rs[3];
+    size_t m_g[3];
+    bool m_ld[3], m_st[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int idx = tid + THREADS * k;
+        bool on = idx < 2 * 3 * W;
+        idx = on ? idx : 0;
+        int f = (idx % (3 * W)) / W, mlc = idx % W, qq = g.qs + mlc;
+        bool cv = on && qq >= 0 && qq < nj;
+        m_rs[k] = idx / (3 * W);
+        m_lds[k] = f * W + sw_cs<G>(mlc);
+        m_g[k] = (size_t)f * npts + (size_t)(cv ? qq : 0);
+        m_ld[k] = cv;
+        m_st[k] = cv && mlc >= SW_HALO && mlc < SW_HALO + OUT;
+        if (!on) m_lds[k] = -1;
+    }
+    constexpr int NIMG = 2 * (W + 2);
+    constexpr int KIMG = (NIMG + THREADS - 1) / THREADS;
+    int i_lds[KIMG], i_rs[KIMG], i_fc[KIMG];
+    bool i_ok[KIMG];
+    if (Pol::kHasImage) {
+#pragma unroll
+        for (int k = 0; k < KIMG; ++k) {
+            int idx = tid + THREADS * k;
+            bool on = idx < NIMG;
+            idx = on ? idx : 0;
+            int lci = idx % (W + 2), fc = g.qs + lci;
+            i_rs[k] = idx / (W + 2);
+            i_lds[k] = on ? sw_ci<G>(lci) : -1;
+            i_ok[k] = on && fc >= 0 && fc <= nj + 1;
+            i_fc[k] = i_ok[k] ? fc : 0;
+        }
+    }
+
+    const int stage_row_off = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
+    const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
+    double bn0 = 0, bn1 = 0, bn2 = 0;  // b of the stage's point for the NEXT step (prefetched)
+    const int s_end = TI / 2 + 4;
+    for (int s = -2; s <= s_end; ++s) {
+        const int e = 2 * s;
+        // ring slots of the two rows that leave (e-10, e-9) / enter (e+2, e+3) the ring: the same slots
+        const int slotA = sw_slot(e + 2), slotB = sw_slot(e + 3);
+        // (1) write-out of the rows that became final: relative rows e-10, e-9
+        {
+            const int rrA = e - 10, rrB = e - 9, pA = g.p0 + rrA, pB = g.p0 + rrB;
+            const bool okA = rrA >= 0 && rrA < TI && pA >= 0 && pA < ni;
+            const bool okB = rrB >= 0 && rrB < TI && pB >= 0 && pB < ni;
+            if (okA || okB) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const bool rowok = m_rs[k] ? okB : okA;
+                    if (m_st[k] && rowok) {
+                        const int slot = m_rs[k] ? slotB : slotA;
+                        const size_t prow = (size_t)(m_rs[k] ? pB : pA) * nj;
+                        xout[prow + m_g[k]] = xs[slot * 3 * W + m_lds[k]];
+                    }
+                }
+            }
+        }
+        // (2) global loads of relative rows e+2, e+3 into registers
+        VT lx[3];
+        double li[KIMG];
+        const bool do_load = (e + 2 <= TI + 1);
+        {
+            const int pA = g.p0 + e + 2, pB = pA + 1;
+            const bool okA = do_load && xin && pA >= 0 && pA < ni, okB = do_load && xin && pB >= 0 && pB < ni;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lx[k] = (VT)0;
+                const bool rowok = m_rs[k] ? okB : okA;
+                if (m_ld[k] && rowok) lx[k] = xin[(size_t)(m_rs[k] ? pB : pA) * nj + m_g[k]];
+            }
+            if (Pol::kHasImage) {
+                const int fA = pA + 1, fB = pB + 1;   // full-image rows
+                const bool iokA = do_load && fA >= 0 && fA <= ni + 1, iokB = do_load && fB >= 0 && fB <= ni + 1;
+#pragma unroll
+                for (int k = 0; k < KIMG; ++k) {
+                    li[k] = 0.0;
+                    const bool rowok = i_rs[k] ? iokB : iokA;
+                    if (i_ok[k] && rowok) li[k] = img[(size_t)(i_rs[k] ? fB : fA) * pol.Nj + i_fc[k]];
+                }
+            }
+        }
+        // (3) this step's b (prefetched during the previous step) and the prefetch for the next step
+        double b0 = bn0, b1 = bn1, b2 = bn2;
+        {
+            const int rrn = e + 2 + stage_row_off, pn = g.p0 + rrn;
+            if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni) {
+                const VT* brow = bp + (size_t)pn * nj;
+                bn0 = (double)brow[bcol]; bn1 = (double)brow[npts + bcol]; bn2 = (double)brow[2 * npts + bcol];
+            }
+        }
+        // (4) the stage of this wave (row quantities are scalar for the colour waves of GeoA)
+        {
+            const int rr = e + stage_row_off, p = g.p0 + rr;
+            if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
+                const SweepRows rw = sweep_rows<G>(g, rr, (size_t)L.hj, L.sub);
+                double u, w, gm;
+                pol.template update<G, VT>(cc, rw, xs, im, pair, b0, b1, b2, u, w, gm);
+                VT* row = xs + rw.pC + cc.cC;
+                row[0] = (VT)u; row[W] = (VT)w; row[2 * W] = (VT)gm;
+            }
+        }
+        // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
+        if (do_load) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (m_lds[k] >= 0) xs[(m_rs[k] ? slotB : slotA) * 3 * W + m_lds[k]] = lx[k];
+            if (Pol::kHasImage) {
+#pragma unroll
+                for (int k = 0; k < KIMG; ++k)
+                    if (i_lds[k] >= 0) im[(i_rs[k] ? slotB : slotA) * IW + i_lds[k]] = li[k];
+            }
+        }
+        __syncthreads();
+    }
+}
 
 }  // namespace vof
