@@ -77,6 +77,7 @@ struct vof_ctx {
     bool hierarchy_float = false;
     bool fused = true;   // fused streaming 4-colour sweeps (false: one launch per colour)
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
+    bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     // profiler
     bool prof = false;
     int prof_kid = -1, prof_level = -1;  // filter (-1 = any)
@@ -199,12 +200,43 @@ void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np
 
 // y = A_l x (mode 0) or y = b - A_l x (mode 1); XT/BT/YT storage types (level 0 matrix-free),
 // stored levels use one type for all three.
+// Geometry of the streaming level-0 operator kernel: 128-column strips, bands of <= 128 rows (even height).
+struct ApplyGrid { int TI, nblk; dim3 grid; };
+ApplyGrid apply_grid(const vof_ctx* c, int np) {
+    const Level& lv = c->L[0];
+    int nb = (lv.ni + 127) / 128;
+    int TI = std::max(2, (((lv.ni + nb - 1) / nb + 1) / 2) * 2);
+    ApplyGrid g;
+    g.TI = TI;
+    g.grid = dim3((lv.nj + AP_OUT - 1) / AP_OUT, (lv.ni + TI - 1) / TI, np);
+    g.nblk = g.grid.x * g.grid.y;
+    return g;
+}
+
+// y = A x (mode 0) or y = b - A x (mode 1) on the matrix-free level 0.  Optional fused reductions into
+// c->partials (slot 0: y.dotvec, or y.y when dotvec == nullptr; slot 1: y.y when both are asked for); the
+// number of per-pair partials is apply_grid().nblk.
 template <typename XT, typename BT, typename YT>
-void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np, const int* active) {
+void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np, const int* active,
+                  const double* dotvec = nullptr, int want_yy = 0) {
     Level& lv = c->L[0];
-    dim3 g = grid2d(lv.ni, lv.nj, np);
-    const double bytes = (8.0 + 3.0 * sizeof(XT) + 3.0 * sizeof(YT) + (mode ? 3.0 * sizeof(BT) : 0.0)) * lv.npts;
+    const double bytes = (8.0 + 3.0 * sizeof(XT) + 3.0 * sizeof(YT) + (mode ? 3.0 * sizeof(BT) : 0.0) +
+                          (dotvec ? 24.0 : 0.0)) * lv.npts;
     Prof p(c, VOF_K_APPLY0, 0, bytes);
+    if (c->stream_apply) {
+        ApplyGrid ag = apply_grid(c, np);
+        double* part = (dotvec || want_yy) ? c->partials : nullptr;
+        if (mode)
+            k_stream_apply0<1, XT, BT, YT><<<ag.grid, AP_THREADS, 0, c->stream>>>(
+                c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, ag.TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
+                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active);
+        else
+            k_stream_apply0<0, XT, BT, YT><<<ag.grid, AP_THREADS, 0, c->stream>>>(
+                c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, ag.TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
+                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active);
+        return;
+    }
+    dim3 g = grid2d(lv.ni, lv.nj, np);
     if (mode)
         k_apply0<1, XT, BT, YT><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
                                                             c->prm.speed_alpha, c->prm.remodelling_alpha,
@@ -237,15 +269,23 @@ void apply_level_t(vof_ctx* c, int l, const VT* x, const VT* b, VT* y, int mode,
     else apply_stored_t<VT>(c, l, x, b, y, mode, np, active);
 }
 
-// Krylov-level products on level 0 with FP64 results: out = A y (y V-typed) and out = b - A x (all double)
-void krylov_apply(vof_ctx* c, const void* y, double* out, int np, const int* active) {
-    if (c->L[0].C) { apply_stored_t<double>(c, 0, (const double*)y, nullptr, out, 0, np, active); return; }
-    if (c->vfloat) apply_fine_t<float, double, double>(c, (const float*)y, nullptr, out, 0, np, active);
-    else apply_fine_t<double, double, double>(c, (const double*)y, nullptr, out, 0, np, active);
+// Krylov-level products on level 0 with FP64 results: out = A y (y V-typed) and out = b - A x (all double).
+// When `fuse` is set and the streaming kernel is in use, the reductions (out.dotvec and/or out.out) are fused
+// into the operator kernel and the function returns the number of per-pair partials it wrote; otherwise 0
+// (the caller then launches k_dot2).
+int krylov_apply(vof_ctx* c, const void* y, double* out, int np, const int* active, const double* dotvec = nullptr,
+                 int want_yy = 0) {
+    if (c->L[0].C) { apply_stored_t<double>(c, 0, (const double*)y, nullptr, out, 0, np, active); return 0; }
+    const bool fuse = c->stream_apply && (dotvec || want_yy);
+    if (c->vfloat) apply_fine_t<float, double, double>(c, (const float*)y, nullptr, out, 0, np, active, fuse ? dotvec : nullptr, fuse ? want_yy : 0);
+    else apply_fine_t<double, double, double>(c, (const double*)y, nullptr, out, 0, np, active, fuse ? dotvec : nullptr, fuse ? want_yy : 0);
+    return fuse ? apply_grid(c, np).nblk : 0;
 }
-void residual_d(vof_ctx* c, const double* x, const double* b, double* out, int np, const int* active) {
-    if (c->L[0].C) apply_stored_t<double>(c, 0, x, b, out, 1, np, active);
-    else apply_fine_t<double, double, double>(c, x, b, out, 1, np, active);
+int residual_d(vof_ctx* c, const double* x, const double* b, double* out, int np, const int* active, int want_norm = 0) {
+    if (c->L[0].C) { apply_stored_t<double>(c, 0, x, b, out, 1, np, active); return 0; }
+    const bool fuse = c->stream_apply && want_norm;
+    apply_fine_t<double, double, double>(c, x, b, out, 1, np, active, nullptr, fuse ? 1 : 0);
+    return fuse ? apply_grid(c, np).nblk : 0;
 }
 
 template <typename VT>
@@ -488,25 +528,25 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));
           VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
         vcycle(c, c->ky, vrhs_p, np, act);                         // y = M p
-        krylov_apply(c, c->ky, c->kv, np, act);                    // v = A y
-        { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); }
-        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+        int nb1 = krylov_apply(c, c->ky, c->kv, np, act, c->krh, 0);   // v = A y, fused (r^, v)
+        if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, nb1, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5 + (c->vfloat ? 8.0 : 8.0) * len);
           VDISPATCH(c, (k_update_s<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, c->kr, c->kv, len, c->sc, c->partials, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_S><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
         vcycle(c, c->ky, vrhs_s, np, act);                         // z = M s
-        krylov_apply(c, c->ky, c->kt, np, act);                    // t = A z
-        { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); }
-        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+        int nb2 = krylov_apply(c, c->ky, c->kt, np, act, c->kr, 1);    // t = A z, fused (t, s) and (t, t)
+        if (!nb2) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); nb2 = c->nblk; }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, nb2, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5 + (c->vfloat ? 4.0 : 8.0) * len);
           VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, c->kr, c->kt, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
     // independent residual (OF.py:1150-1151)
     c->cur_units = np;
-    residual_d(c, c->kx, c->kb, c->kt, np, nullptr);
-    { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); }
-    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+    int nb3 = residual_d(c, c->kx, c->kb, c->kt, np, nullptr, 1);
+    if (!nb3) { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); nb3 = c->nblk; }
+    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, nb3, c->active, P.rtol, P.max_iterations); }
     // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
     { Prof p(c, VOF_K_FUNCTIONALS, 0);
       k_functionals<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, P.speed_alpha,
@@ -640,6 +680,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
         c->geo_b_fine = e[0] == 'B';
         c->geo_b_stored = e[0] && e[1] == 'B';
     }
+    if (const char* e = getenv("VOF_STREAM_APPLY")) c->stream_apply = e[0] != '0';
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
     c->L.push_back(l0);
@@ -671,7 +712,11 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (int rc = dev_alloc(c, &c->W, (size_t)B * c->nd * 2 * c->nd)) return rc;
     if (int rc = dev_alloc(c, &c->invT, (size_t)B * c->nd * c->nd)) return rc;
     c->nblk = (int)std::min<size_t>(256, std::max<size_t>(1, (len0 + 4 * RBLK - 1) / (4 * RBLK)));
-    if (int rc = dev_alloc(c, &c->partials, (size_t)B * 3 * c->nblk)) return rc;
+    {
+        int nb = (l0.ni + 127) / 128, TI = std::max(2, (((l0.ni + nb - 1) / nb + 1) / 2) * 2);
+        int nblk_apply = ((l0.nj + AP_OUT - 1) / AP_OUT) * ((l0.ni + TI - 1) / TI);
+        if (int rc = dev_alloc(c, &c->partials, (size_t)B * 3 * std::max(c->nblk, nblk_apply))) return rc;
+    }
     if (int rc = dev_alloc(c, &c->sc, (size_t)B)) return rc;
     if (int rc = dev_alloc(c, &c->active, (size_t)B)) return rc;
     if (int rc = dev_alloc(c, &c->func3, (size_t)B * 3)) return rc;

@@ -1184,4 +1184,148 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     }
 }
 
+// ==========================================================================================
+// k_stream_apply0: level-0 operator application y = A x (MODE 0) or y = b - A x (MODE 1), matrix-free,
+// streaming over rows through an LDS ring (every array is read once, coalesced; the 9-point neighbourhood and
+// the 3x3 image neighbourhood come from LDS).  A block owns a 128-column aligned strip (+1 halo column each
+// side) and a band of TI rows; per step the two wave pairs compute two rows.  Optional fused reductions:
+// slot 0 = sum y * dotvec (or y * y if dotvec == nullptr and want_yy), slot 1 = sum y * y (dotvec && want_yy);
+// per-block partials are written at index blockIdx.y * gridDim.x + blockIdx.x (deterministic two-stage sum).
+// ==========================================================================================
+constexpr int AP_OUT = 128, AP_W = 132, AP_RING = 8, AP_THREADS = 256;
+
+template <int MODE, typename XT, typename BT, typename YT>
+__global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
+    const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj, int TI, double alpha, double beta,
+    int quirks, const XT* __restrict__ x, const BT* __restrict__ b, YT* __restrict__ y,
+    const double* __restrict__ dotvec, int want_yy, double* __restrict__ partials, int nblk,
+    const int* __restrict__ active) {
+    __shared__ XT xs[AP_RING * 3 * AP_W];
+    __shared__ double im[AP_RING * AP_W];
+    __shared__ double red[2][AP_THREADS / 64];
+    const int pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    const int tid = threadIdx.x;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);   // which of the two rows of a step
+    const int col = tid & 127;
+    const int q0 = blockIdx.x * AP_OUT, p0 = blockIdx.y * TI;
+    const int q = q0 + col;
+    const bool col_ok = q < nj;
+    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const XT* xp = x + off;
+    const double* img = frames + (size_t)pair * frame_stride;
+    // x ring local column of q is col + 1 (local 0 <-> q0 - 1); ghost columns fold onto their mirror
+    const bool oL = q - 1 < 0, oR = q + 1 >= nj;
+    const int cC = col + 1, cL = oL ? col + 2 : col, cR = oR ? col : col + 2;
+    // image ring local column li <-> full-image column q0 + li; point q uses li = col, col+1, col+2
+    double s0 = 0.0, s1 = 0.0;
+    const int nsteps = TI / 2;
+    for (int s = -2; s < nsteps; ++s) {
+        const int r = 2 * s;
+        // ---- global loads of relative row r + 3 + half into registers
+        const int rl = r + 3 + half, pl = p0 + rl;
+        const bool row_ld = rl <= TI && pl >= 0 && pl < ni;
+        const bool irow_ld = rl <= TI && pl + 1 >= 0 && pl + 1 <= ni + 1;
+        XT l0 = (XT)0, l1 = (XT)0, l2 = (XT)0, h0 = (XT)0, h1 = (XT)0, h2 = (XT)0;
+        double li0 = 0.0, li1 = 0.0;
+        if (row_ld) {
+            const XT* xr = xp + (size_t)pl * nj;
+            if (col_ok) { l0 = xr[q]; l1 = xr[npts + q]; l2 = xr[2 * npts + q]; }
+            // halo columns q0 - 1 (lane 0) and q0 + 128 (lane 127)
+            const int qh = (col == 0) ? q0 - 1 : q0 + AP_OUT;
+            if ((col == 0 || col == 127) && qh >= 0 && qh < nj) { h0 = xr[qh]; h1 = xr[npts + qh]; h2 = xr[2 * npts + qh]; }
+        }
+        if (irow_ld) {
+            const double* ir = img + (size_t)(pl + 1) * Nj;
+            if (q0 + col <= nj + 1) li0 = ir[q0 + col];
+            if (col < 2 && q0 + 128 + col <= nj + 1) li1 = ir[q0 + 128 + col];
+        }
+        // ---- compute relative row r + half
+        const int rc = r + half, p = p0 + rc;
+        if (s >= 0 && rc < TI && p < ni && col_ok) {
+            const bool oU = p - 1 < 0, oD = p + 1 >= ni;
+            const int sU = ((rc - 1) + AP_RING) & (AP_RING - 1), sC = (rc + AP_RING) & (AP_RING - 1),
+                      sD = ((rc + 1) + AP_RING) & (AP_RING - 1);
+            const double* i0 = im + sU * AP_W;
+            const double* i1 = im + sC * AP_W;
+            const double* i2 = im + sD * AP_W;
+            double imm = i0[col], im0 = i0[col + 1], imp = i0[col + 2];
+            double i0m = i1[col], i00 = i1[col + 1], i0p = i1[col + 2];
+            double ipm = i2[col], ip0 = i2[col + 1], ipp = i2[col + 2];
+            PixCoef k;
+            k.P = i00;
+            k.Dx = (ip0 - im0) / 2;
+            k.Dy = quirks ? k.Dx : (i0p - i0m) / 2;
+            k.Dxx = ip0 + im0 - 2 * i00;
+            k.Dyy = i0p + i0m - 2 * i00;
+            k.Dxy = (ipp - ipm - imp + imm) / 4;
+            const XT* ru = xs + (oU ? sD : sU) * 3 * AP_W;   // ghost row -1 mirrors row 1, ghost row n mirrors n-2
+            const XT* rcn = xs + sC * 3 * AP_W;
+            const XT* rd = xs + (oD ? sU : sD) * 3 * AP_W;
+            const double sUL = (oU && oL) ? 2.0 : 1.0, sUR = (oU && oR) ? 2.0 : 1.0;
+            const double sDL = (oD && oL) ? 2.0 : 1.0, sDR = (oD && oR) ? 2.0 : 1.0;
+            Nbr n;
+            n.u[0] = sUL * (double)ru[cL]; n.w[0] = sUL * (double)ru[AP_W + cL];
+            n.u[1] = (double)ru[cC];       n.w[1] = (double)ru[AP_W + cC];       n.g[1] = (double)ru[2 * AP_W + cC];
+            n.u[2] = sUR * (double)ru[cR]; n.w[2] = sUR * (double)ru[AP_W + cR];
+            n.u[3] = (double)rcn[cL];      n.w[3] = (double)rcn[AP_W + cL];      n.g[3] = (double)rcn[2 * AP_W + cL];
+            n.u[4] = (double)rcn[cC];      n.w[4] = (double)rcn[AP_W + cC];      n.g[4] = (double)rcn[2 * AP_W + cC];
+            n.u[5] = (double)rcn[cR];      n.w[5] = (double)rcn[AP_W + cR];      n.g[5] = (double)rcn[2 * AP_W + cR];
+            n.u[6] = sDL * (double)rd[cL]; n.w[6] = sDL * (double)rd[AP_W + cL];
+            n.u[7] = (double)rd[cC];       n.w[7] = (double)rd[AP_W + cC];       n.g[7] = (double)rd[2 * AP_W + cC];
+            n.u[8] = sDR * (double)rd[cR]; n.w[8] = sDR * (double)rd[AP_W + cR];
+            double y0, y1, y2;
+            offdiag0(k, alpha, beta, n, y0, y1, y2);
+            const double P = k.P;
+            y0 += (P * (k.Dxx - 2 * P) - 4 * alpha) * n.u[4] + P * k.Dxy * n.w[4];
+            y1 += (P * (k.Dyy - 2 * P) - 4 * alpha) * n.w[4] + P * k.Dxy * n.u[4];
+            y2 += (-1 - 4 * beta) * n.g[4] + k.Dx * n.u[4] + k.Dy * n.w[4];
+            const size_t idx = (size_t)p * nj + q;
+            if (MODE == 1) {
+                y0 = (double)b[off + idx] - y0;
+                y1 = (double)b[off + npts + idx] - y1;
+                y2 = (double)b[off + 2 * npts + idx] - y2;
+            }
+            y[off + idx] = (YT)y0;
+            y[off + npts + idx] = (YT)y1;
+            y[off + 2 * npts + idx] = (YT)y2;
+            if (dotvec) {
+                s0 += y0 * dotvec[off + idx] + y1 * dotvec[off + npts + idx] + y2 * dotvec[off + 2 * npts + idx];
+                if (want_yy) s1 += y0 * y0 + y1 * y1 + y2 * y2;
+            } else if (want_yy) {
+                s0 += y0 * y0 + y1 * y1 + y2 * y2;
+            }
+        }
+        // ---- loaded row -> LDS ring
+        if (rl <= TI) {
+            const int sl = (rl + AP_RING) & (AP_RING - 1);
+            XT* xr = xs + sl * 3 * AP_W;
+            xr[col + 1] = l0; xr[AP_W + col + 1] = l1; xr[2 * AP_W + col + 1] = l2;
+            if (col == 0 || col == 127) {
+                const int ch = (col == 0) ? 0 : AP_OUT + 1;
+                xr[ch] = h0; xr[AP_W + ch] = h1; xr[2 * AP_W + ch] = h2;
+            }
+            double* ir = im + sl * AP_W;
+            ir[col] = li0;
+            if (col < 2) ir[128 + col] = li1;
+        }
+        __syncthreads();
+    }
+    if (partials && (dotvec || want_yy)) {
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane == 0) { red[0][wv] = s0; red[1][wv] = s1; }
+        __syncthreads();
+        if (tid == 0) {
+            double t0 = 0, t1 = 0;
+            for (int i = 0; i < AP_THREADS / 64; ++i) { t0 += red[0][i]; t1 += red[1][i]; }
+            const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+            double* pp = partials + ((size_t)pair * 3) * nblk + blk;
+            pp[0] = t0;
+            if (dotvec && want_yy) pp[nblk] = t1;
+        }
+    }
+}
+
 }  // namespace vof
