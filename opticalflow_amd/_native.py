@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libvof.so")
+# VOF_LIB: alternative build of the library (A/B experiments); default is the in-tree libvof.so
+LIB_PATH = os.environ.get("VOF_LIB") or os.path.join(HERE, "csrc", "libvof.so")
 
 K_NAMES = ["rhs", "apply0", "gs0", "gs", "residual", "restrict", "prolong", "galerkin0", "galerkin",
            "coarse_setup", "coarse_solve", "vector", "reduce", "finalize", "functionals"]

@@ -897,11 +897,14 @@ struct SweepFine {
     double alpha, beta;
     int quirks;
     static constexpr bool kHasImage = true;
+    static constexpr int kPrefetch = 0;   // no per-point coefficient planes
+    typedef float coef_t;
+    __device__ __forceinline__ void prefetch(const SweepCols&, size_t, int, coef_t*) const {}
 
     template <class G, typename VT>
     __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs, const double* im,
-                                           int /*pair*/, double b0, double b1, double b2, double& u, double& w,
-                                           double& gm) const {
+                                           int /*pair*/, const coef_t* /*cf*/, double b0, double b1, double b2,
+                                           double& u, double& w, double& gm) const {
         constexpr int W = G::W;
         const double* r0 = im + rw.iU;
         const double* r1 = im + rw.iC;
@@ -954,13 +957,27 @@ struct SweepStored {
     size_t frame_stride = 0;
     int Nj = 0;
 
+    // float stencils: the 81 coefficients of the NEXT step's point are loaded into registers before the step
+    // barrier (the registers of the current step are dead by then), so their latency overlaps the barrier and
+    // the next step's row traffic.  double stencils (162 registers) are loaded at use.
+#ifdef SW_NO_PREFETCH
+    static constexpr int kPrefetch = 0;
+#else
+    static constexpr int kPrefetch = sizeof(CT) == 4 ? 81 : 0;
+#endif
+    typedef CT coef_t;
+    __device__ __forceinline__ void prefetch(const SweepCols& cc, size_t rowpart, int pair, coef_t* cf) const {
+        const CT* sp = C + (size_t)pair * 81 * plane + rowpart + cc.cq;
+#pragma unroll
+        for (int t = 0; t < 81; ++t) cf[t] = sp[(size_t)t * plane];
+    }
+
     template <class G, typename VT>
     __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs,
-                                           const double* /*im*/, int pair, double b0, double b1, double b2, double& u,
-                                           double& w, double& gm) const {
+                                           const double* /*im*/, int pair, const coef_t* cf, double b0, double b1,
+                                           double b2, double& u, double& w, double& gm) const {
         constexpr int W = G::W;
-        const CT* sp = C + (size_t)pair * 81 * plane + rw.cp;
-        const size_t cq = cc.cq;
+        const CT* sp = C + (size_t)pair * 81 * plane + rw.cp + cc.cq;
         const int rowo[3] = {rw.pU, rw.pC, rw.pD};
         const int colo[3] = {cc.uL, cc.cC, cc.uR};
         double y0 = 0, y1 = 0, y2 = 0;
@@ -971,15 +988,18 @@ struct SweepStored {
             for (int bb = 0; bb < 3; ++bb) {
                 if (a == 1 && bb == 1) continue;
                 double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
-                const CT* cb = sp + (size_t)((a * 3 + bb) * 9) * plane;
-                y0 += (double)cb[cq] * xu + (double)(cb + plane)[cq] * xw + (double)(cb + 2 * plane)[cq] * xg;
-                y1 += (double)(cb + 3 * plane)[cq] * xu + (double)(cb + 4 * plane)[cq] * xw + (double)(cb + 5 * plane)[cq] * xg;
-                y2 += (double)(cb + 6 * plane)[cq] * xu + (double)(cb + 7 * plane)[cq] * xw + (double)(cb + 8 * plane)[cq] * xg;
+                const int t0 = (a * 3 + bb) * 9;
+                double c9[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) c9[t] = kPrefetch ? (double)cf[t0 + t] : (double)sp[(size_t)(t0 + t) * plane];
+                y0 += c9[0] * xu + c9[1] * xw + c9[2] * xg;
+                y1 += c9[3] * xu + c9[4] * xw + c9[5] * xg;
+                y2 += c9[6] * xu + c9[7] * xw + c9[8] * xg;
             }
         }
         double D[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) D[t] = (double)(sp + (size_t)(36 + t) * plane)[cq];
+        for (int t = 0; t < 9; ++t) D[t] = kPrefetch ? (double)cf[36 + t] : (double)sp[(size_t)(36 + t) * plane];
         solve3(D, b0 - y0, b1 - y1, b2 - y2, u, w, gm);
     }
 };
@@ -1103,6 +1123,11 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     const int stage_row_off = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
     const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
     double bn0 = 0, bn1 = 0, bn2 = 0;  // b of the stage's point for the NEXT step (prefetched)
+    typename Pol::coef_t cf[Pol::kPrefetch ? Pol::kPrefetch : 1];   // coefficients of the next step's point
+    if (Pol::kPrefetch) {
+#pragma unroll
+        for (int t = 0; t < (Pol::kPrefetch ? Pol::kPrefetch : 1); ++t) cf[t] = 0;
+    }
     const int s_end = TI / 2 + 4;
     for (int s = -2; s <= s_end; ++s) {
         const int e = 2 * s;
@@ -1164,7 +1189,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
             if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
                 const SweepRows rw = sweep_rows<G>(g, rr, (size_t)L.hj, L.sub);
                 double u, w, gm;
-                pol.template update<G, VT>(cc, rw, xs, im, pair, b0, b1, b2, u, w, gm);
+                pol.template update<G, VT>(cc, rw, xs, im, pair, cf, b0, b1, b2, u, w, gm);
                 VT* row = xs + rw.pC + cc.cC;
                 row[0] = (VT)u; row[W] = (VT)w; row[2 * W] = (VT)gm;
             }
@@ -1179,6 +1204,12 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
                 for (int k = 0; k < KIMG; ++k)
                     if (i_lds[k] >= 0) im[(i_rs[k] ? slotB : slotA) * IW + i_lds[k]] = li[k];
             }
+        }
+        // (6) coefficient prefetch for the next step's point (stored float stencils)
+        if (Pol::kPrefetch) {
+            const int rrn = e + 2 + stage_row_off, pn = g.p0 + rrn;
+            if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)
+                pol.prefetch(cc, (size_t)((pn & 1) << 1) * L.sub + (size_t)(pn >> 1) * L.hj, pair, cf);
         }
         __syncthreads();
     }
