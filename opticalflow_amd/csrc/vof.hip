@@ -319,7 +319,8 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
     int TI = std::max(2, (((rows + nb - 1) / nb + 1) / 2) * 2);
     const bool geoB = (l > 0) ? c->geo_b_stored : c->geo_b_fine;
     const int out = geoB ? GeoB::OUT : GeoA::OUT, W = geoB ? GeoB::W : GeoA::W, IW = geoB ? GeoB::IW : GeoA::IW;
-    dim3 g((lv.nj + (geoB ? 0 : po) + out - 1) / out, (rows + TI - 1) / TI, np);
+    const int nx = (lv.nj + (geoB ? 0 : po) + out - 1) / out, ny = (rows + TI - 1) / TI;
+    dim3 g((unsigned)nx * ny * np, 1, 1);
     const double vs = sizeof(VT);
     if (l == 0 && lv.C == nullptr) {
         Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // I + b(3) + x(3) in, x(3) out
@@ -327,20 +328,20 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
         pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double);
-        if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
-        else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+        if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+        else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
     } else {
         const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
         Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
         if (c->hierarchy_float && l > 0) {
             SweepStored<float> pol; pol.C = (const float*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
-            if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
-            else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+            else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
         } else {
             SweepStored<double> pol; pol.C = (const double*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
-            if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
-            else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+            else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
         }
     }
 }

@@ -1021,23 +1021,31 @@ __device__ __forceinline__ SweepRows sweep_rows(const SweepGeom& g, int rr, size
     return r;
 }
 
+// Launched on a 1-D grid of nx * ny * nz blocks.  Blocks are dealt round-robin over the 8 XCDs (each with its own
+// L2); the remap below gives every XCD a contiguous range of logical blocks, so the neighbouring strips of a band
+// (which read each other's halo lines of x, b and of the coefficient planes) run on the same XCD at about the
+// same time and find those lines in its L2.  Pure speed: any placement gives the same result.
 template <class Pol, class G, typename VT>
-__global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po,
+__global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
                                                const VT* __restrict__ x_in, VT* __restrict__ x_out,
                                                const VT* __restrict__ b, const int* __restrict__ active) {
     constexpr int W = G::W, IW = G::IW, OUT = G::OUT, THREADS = G::THREADS;
     extern __shared__ double sw_lds[];
     VT* xs = reinterpret_cast<VT*>(sw_lds);                                                     // [SW_RING][3][W]
     double* im = reinterpret_cast<double*>(reinterpret_cast<char*>(sw_lds) + SW_RING * 3 * W * sizeof(VT));  // [SW_RING][IW]
-    const int pair = blockIdx.z;
+    const unsigned nblocks = (unsigned)nx * ny * nz;
+    unsigned lb = blockIdx.x;
+    if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // bijective when nblocks % 8 == 0
+    const int bx = lb % nx, by = (lb / nx) % ny;
+    const int pair = lb / (nx * ny);
     if (active && !active[pair]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the stage's row arithmetic scalar
     SweepGeom g;
     g.ni = ni; g.nj = nj; g.TI = TI;
-    g.p0 = blockIdx.y * TI - po;
+    g.p0 = by * TI - po;
     // GeoB: strips always 128-aligned, po only swaps the column parity of the stages.  GeoA: strip origin shifted by po.
-    const int q0 = G::HALO_WAVE ? blockIdx.x * OUT : blockIdx.x * OUT - po;
+    const int q0 = G::HALO_WAVE ? bx * OUT : bx * OUT - po;
     g.qs = q0 - SW_HALO;
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     const VT* xin = x_in ? x_in + off : nullptr;
