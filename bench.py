@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (test)")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel HIP-event table (stderr)")
     args = ap.parse_args()
 
@@ -106,8 +107,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from opticalflow_amd import _native
@@ -123,7 +128,7 @@ def main():
     gm = torch.empty_like(vx)
     sp = torch.empty_like(vx)
     gathered = None
-    if world > 1 and not args.no_allgather:
+    if use_dist and not args.no_allgather:
         gathered = [torch.empty((world * P, n, n), dtype=torch.float64, device=dev) for _ in range(3)]
     torch.cuda.synchronize()
 
@@ -145,7 +150,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
     cnt, ms = solver.profile_get(dom_name, dom_level)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -222,7 +227,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     solver.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
