@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="float32", choices=["float64", "float32"])
     ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--nu-pre", type=int, default=2)
+    ap.add_argument("--nu-post", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (test)")
@@ -137,7 +139,8 @@ def main():
     B = args.pairs_in_flight or largest_batch(P, per_pair, 0.7 * free)
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
                                     coarse_precision={"float64": 0, "float32": 1}[args.coarse_precision],
-                                    vcycle_precision={"float64": 0, "float32": 1}[args.vcycle_precision])
+                                    vcycle_precision={"float64": 0, "float32": 1}[args.vcycle_precision],
+                                    nu_pre=args.nu_pre, nu_post=args.nu_post)
     solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
