@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32"])
     ap.add_argument("--nu-pre", type=int, default=2)
     ap.add_argument("--nu-post", type=int, default=2)
+    ap.add_argument("--nu-pre-coarse", type=int, default=1)
+    ap.add_argument("--nu-post-coarse", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (test)")
@@ -140,7 +142,8 @@ def main():
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
                                     coarse_precision={"float64": 0, "float32": 1}[args.coarse_precision],
                                     vcycle_precision={"float64": 0, "float32": 1}[args.vcycle_precision],
-                                    nu_pre=args.nu_pre, nu_post=args.nu_post)
+                                    nu_pre=args.nu_pre, nu_post=args.nu_post, nu_pre_coarse=args.nu_pre_coarse,
+                                    nu_post_coarse=args.nu_post_coarse)
     solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
@@ -215,6 +218,7 @@ def main():
         "config": {"workload": f"{n}x{n}x{T} synthetic translating texture per GPU (seed {seed}), speed_alpha=1, "
                                f"remodelling_alpha=1e4, rtol={args.rtol:g}, all {P} pairs solved to the stopping rule",
                    "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
+                   "sweeps": [args.nu_pre, args.nu_post, args.nu_pre_coarse, args.nu_post_coarse],
                    "allgather": gathered is not None,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),

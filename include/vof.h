@@ -43,7 +43,8 @@ typedef struct vof_params {
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
     int32_t coarse_precision;  /* 1 (default): float32 storage of the Galerkin stencils; 0: float64 */
     int32_t vcycle_precision;  /* 0 (default): float64 V-cycle vectors; 1: float32 storage (FP64 arithmetic, FP64 Krylov) */
-    int32_t reserved[2];
+    int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
+    int32_t nu_post_coarse;
 } vof_params;
 
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */

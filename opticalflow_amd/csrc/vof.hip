@@ -380,12 +380,14 @@ void vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) 
     if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return; }
     Level& lv = c->L[l];
     Level& nx = c->L[l + 1];
-    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, c->prm.nu_pre, true, false, np, active);
+    const int nu1 = (l > 0 && c->prm.nu_pre_coarse > 0) ? c->prm.nu_pre_coarse : c->prm.nu_pre;
+    const int nu2 = (l > 0 && c->prm.nu_post_coarse > 0) ? c->prm.nu_post_coarse : c->prm.nu_post;
+    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu1, true, false, np, active);
     apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
     restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
     vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
     prolong_add_level_t<VT>(c, l, x, (const VT*)nx.x, np, active);
-    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, c->prm.nu_post, false, true, np, active);
+    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active);
 }
 
 void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
@@ -577,6 +579,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (!p) { c->err = "params is NULL"; return -1; }
     if (!(p->delta_x != 0.0) || !(p->delta_t != 0.0)) { c->err = "delta_x and delta_t must be non-zero"; return -1; }
     if (p->nu_pre < 0 || p->nu_post < 0 || p->nu_pre + p->nu_post == 0) { c->err = "nu_pre + nu_post must be > 0"; return -1; }
+    if (p->nu_pre_coarse < 0 || p->nu_post_coarse < 0) { c->err = "nu_*_coarse must be >= 0"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
     if (p->vcycle_precision != 0 && p->vcycle_precision != 1) { c->err = "vcycle_precision must be 0 or 1"; return -1; }
@@ -602,8 +605,10 @@ void vof_default_params(vof_params* p) {
     p->delta_t = 1.0;
     p->rtol = 1e-6;                // OF.py:1120
     p->max_iterations = 1000;      // OF.py:1120
-    p->nu_pre = 2;
+    p->nu_pre = 2;                 // V(2,2) on level 0 ...
     p->nu_post = 2;
+    p->nu_pre_coarse = 1;          // ... V(1,1) on the stored-stencil levels (measured best time to solution)
+    p->nu_post_coarse = 1;
     p->reference_quirks = 1;
     p->coarse_precision = 1;       // float32 storage of the Galerkin stencils (preconditioner only)
     p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)

@@ -87,6 +87,7 @@ def variational_optical_flow(movie,
                              max_pairs_in_flight=None,
                              coarse_precision="float32",
                              vcycle_precision="float64",
+                             multigrid_sweeps=None,
                              verbose=False,
                              return_stats=False):
     """Variational optical flow with remodelling on an image stack, on one MI355X.
@@ -108,7 +109,8 @@ def variational_optical_flow(movie,
         ``reference_quirks`` (True keeps OF.py:698-699 'dy'=='dx' and the OF.py:1205
         ``speed_functional`` assignment), ``device``, ``max_pairs_in_flight``, ``coarse_precision`` /
         ``vcycle_precision`` (storage precision inside the multigrid preconditioner only; the Krylov
-        iteration, the stopping rule and the result are float64 either way),
+        iteration, the stopping rule and the result are float64 either way), ``multigrid_sweeps``
+        (block-GS sweeps per V-cycle: ``(pre, post)`` on level 0 and optionally ``(pre, post)`` on the coarse levels),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals).
     """
@@ -131,6 +133,11 @@ def variational_optical_flow(movie,
         reference_quirks=int(bool(reference_quirks)),
         coarse_precision={"float64": 0, "float32": 1}[coarse_precision],
         vcycle_precision={"float64": 0, "float32": 1}[vcycle_precision])
+    if multigrid_sweeps is not None:     # (pre, post) on level 0 [, (pre, post) on the coarse levels]
+        ms = tuple(int(v) for v in multigrid_sweeps)
+        params.nu_pre, params.nu_post = ms[0], ms[1]
+        if len(ms) == 4:
+            params.nu_pre_coarse, params.nu_post_coarse = ms[2], ms[3]
     if max_pairs_in_flight is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()

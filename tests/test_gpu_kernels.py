@@ -115,7 +115,8 @@ def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, be
 @pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES[1:3])
 def test_vcycle_matches_prototype(native, kind, shape, npairs, alpha, beta, seed):
     mv = make_case(kind, shape, npairs, seed)
-    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, nu_pre_coarse=2,
+                              nu_post_coarse=2)
     with native.Solver(shape[0], shape[1], npairs) as s:
         s.debug_setup(mv, p)
         r = s.debug_rhs()
@@ -212,7 +213,8 @@ def test_vcycle_fused_equals_per_colour(native):
 def test_float32_vcycle_vectors_building_blocks(native, kind, shape, npairs, alpha, beta, seed):
     """vcycle_precision=1: V-cycle vectors stored as float32, arithmetic FP64 -> float32-rounding agreement."""
     mv = make_case(kind, shape, npairs, seed)
-    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, vcycle_precision=1, coarse_precision=1)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, vcycle_precision=1, coarse_precision=1,
+                              nu_pre_coarse=2, nu_post_coarse=2)
     rng = np.random.default_rng(seed)
     with native.Solver(shape[0], shape[1], npairs) as s:
         s.debug_setup(mv, p)
