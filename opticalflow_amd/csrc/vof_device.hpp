@@ -1004,14 +1004,19 @@ struct SweepStored {
     }
 };
 
+__device__ __forceinline__ int sw_wrap(int t) { return t >= SW_RING ? t - SW_RING : t; }   // t in [0, 2 SW_RING)
+
+// slot_e2 = ring slot of relative row e + 2 (kept incrementally by the row loop); rr = e + sro with sro in {0,-2,-5,-7}
 template <class G>
-__device__ __forceinline__ SweepRows sweep_rows(const SweepGeom& g, int rr, size_t hj, size_t sub) {
+__device__ __forceinline__ SweepRows sweep_rows(const SweepGeom& g, int rr, int slot_e2, int sro, size_t hj, size_t sub) {
     constexpr int W = G::W, IW = G::IW;
     SweepRows r;
     const int p = g.p0 + rr;
     r.oU = p - 1 < 0;
     r.oD = p + 1 >= g.ni;
-    const int sU = sw_slot(rr - 1), sC = sw_slot(rr), sD = sw_slot(rr + 1);
+    // rows rr-1, rr, rr+1 are (e+2) + (sro - 3), (sro - 2), (sro - 1); sro - 3 >= -10 > -SW_RING
+    const int sU = sw_wrap(slot_e2 + SW_RING + sro - 3), sC = sw_wrap(slot_e2 + SW_RING + sro - 2),
+              sD = sw_wrap(slot_e2 + SW_RING + sro - 1);
     r.pU = sU * 3 * W; r.pC = sC * 3 * W; r.pD = sD * 3 * W;
     r.xC = r.pC;
     r.xU = r.oU ? r.pD : r.pU;     // ghost row -1 mirrors row 1, ghost row n mirrors row n-2
@@ -1092,39 +1097,55 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     }
     const size_t bcol = col_ok ? (size_t)q : 0;
 
-    // ---- element mapping of the cooperative load-in / write-out: 2 rows x 3 fields x W columns
+    // ---- cooperative load-in / write-out of 2 rows x 3 fields x W columns per step.
+    // GeoA (W = 128, 256 threads): waves {0,1} own row A, waves {2,3} row B, a thread owns one column and the
+    // three fields -> the row is wave-uniform (scalar predicates / offsets), the fields are unrolled.
+    // GeoB (W = 136, 320 threads): generic element mapping.
+    constexpr bool ROWMAP = !G::HALO_WAVE;
+    const int crow = wave >> 1;
+    const int ccol = tid & 127;
+    const int cq = g.qs + ccol;
+    const bool ccv = ROWMAP && cq >= 0 && cq < nj;
+    const bool cown = ccv && ccol >= SW_HALO && ccol < SW_HALO + OUT;
+    const int clds = sw_cs<G>(ccol);
+    const size_t cqg = ccv ? (size_t)cq : 0;
+    const int fc0 = g.qs + ccol, fc1 = g.qs + 128 + ccol;     // full-image columns of image-ring columns ccol, 128 + ccol
+    const bool iv0 = fc0 >= 0 && fc0 <= nj + 1, iv1 = ccol < 2 && fc1 >= 0 && fc1 <= nj + 1;
+    const int ilds0 = sw_ci<G>(ccol), ilds1 = sw_ci<G>(ccol < 2 ? 128 + ccol : 0);
     int m_lds[3], m_rs[3];
     size_t m_g[3];
     bool m_ld[3], m_st[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int idx = tid + THREADS * k;
-        bool on = idx < 2 * 3 * W;
-        idx = on ? idx : 0;
-        int f = (idx % (3 * W)) / W, mlc = idx % W, qq = g.qs + mlc;
-        bool cv = on && qq >= 0 && qq < nj;
-        m_rs[k] = idx / (3 * W);
-        m_lds[k] = f * W + sw_cs<G>(mlc);
-        m_g[k] = (size_t)f * npts + (size_t)(cv ? qq : 0);
-        m_ld[k] = cv;
-        m_st[k] = cv && mlc >= SW_HALO && mlc < SW_HALO + OUT;
-        if (!on) m_lds[k] = -1;
-    }
     constexpr int NIMG = 2 * (W + 2);
     constexpr int KIMG = (NIMG + THREADS - 1) / THREADS;
     int i_lds[KIMG], i_rs[KIMG], i_fc[KIMG];
     bool i_ok[KIMG];
-    if (Pol::kHasImage) {
+    if (!ROWMAP) {
 #pragma unroll
-        for (int k = 0; k < KIMG; ++k) {
+        for (int k = 0; k < 3; ++k) {
             int idx = tid + THREADS * k;
-            bool on = idx < NIMG;
+            bool on = idx < 2 * 3 * W;
             idx = on ? idx : 0;
-            int lci = idx % (W + 2), fc = g.qs + lci;
-            i_rs[k] = idx / (W + 2);
-            i_lds[k] = on ? sw_ci<G>(lci) : -1;
-            i_ok[k] = on && fc >= 0 && fc <= nj + 1;
-            i_fc[k] = i_ok[k] ? fc : 0;
+            int f = (idx % (3 * W)) / W, mlc = idx % W, qq = g.qs + mlc;
+            bool cv = on && qq >= 0 && qq < nj;
+            m_rs[k] = idx / (3 * W);
+            m_lds[k] = f * W + sw_cs<G>(mlc);
+            m_g[k] = (size_t)f * npts + (size_t)(cv ? qq : 0);
+            m_ld[k] = cv;
+            m_st[k] = cv && mlc >= SW_HALO && mlc < SW_HALO + OUT;
+            if (!on) m_lds[k] = -1;
+        }
+        if (Pol::kHasImage) {
+#pragma unroll
+            for (int k = 0; k < KIMG; ++k) {
+                int idx = tid + THREADS * k;
+                bool on = idx < NIMG;
+                idx = on ? idx : 0;
+                int lci = idx % (W + 2), fc = g.qs + lci;
+                i_rs[k] = idx / (W + 2);
+                i_lds[k] = on ? sw_ci<G>(lci) : -1;
+                i_ok[k] = on && fc >= 0 && fc <= nj + 1;
+                i_fc[k] = i_ok[k] ? fc : 0;
+            }
         }
     }
 
@@ -1137,48 +1158,78 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
         for (int t = 0; t < (Pol::kPrefetch ? Pol::kPrefetch : 1); ++t) cf[t] = 0;
     }
     const int s_end = TI / 2 + 4;
-    for (int s = -2; s <= s_end; ++s) {
+    int slotA = sw_slot(-2);   // ring slot of relative row e + 2, advanced by 2 per step
+    for (int s = -2; s <= s_end; ++s, slotA = sw_wrap(slotA + 2)) {
         const int e = 2 * s;
-        // ring slots of the two rows that leave (e-10, e-9) / enter (e+2, e+3) the ring: the same slots
-        const int slotA = sw_slot(e + 2), slotB = sw_slot(e + 3);
-        // (1) write-out of the rows that became final: relative rows e-10, e-9
-        {
-            const int rrA = e - 10, rrB = e - 9, pA = g.p0 + rrA, pB = g.p0 + rrB;
-            const bool okA = rrA >= 0 && rrA < TI && pA >= 0 && pA < ni;
-            const bool okB = rrB >= 0 && rrB < TI && pB >= 0 && pB < ni;
-            if (okA || okB) {
+        // the two rows that leave (e-10, e-9) / enter (e+2, e+3) the ring share the slots slotA, slotA + 1
+        const int slotB = slotA + 1;
+        VT lx[3];
+        double li[KIMG > 2 ? KIMG : 2];
+        const bool do_load = (e + 2 <= TI + 1);
+        if (ROWMAP) {
+            const int slotR = crow ? slotB : slotA;
+            // (1) write-out of the row that became final: relative row e - 10 + crow
+            {
+                const int rrW = e - 10 + crow, pW = g.p0 + rrW;
+                if (rrW >= 0 && rrW < TI && pW >= 0 && pW < ni && cown) {
+                    VT* orow = xout + (size_t)pW * nj + cqg;
+                    const VT* lrow = xs + slotR * 3 * W + clds;
+                    orow[0] = lrow[0]; orow[npts] = lrow[W]; orow[2 * npts] = lrow[2 * W];
+                }
+            }
+            // (2) global loads of relative row e + 2 + crow into registers
+            const int pL = g.p0 + e + 2 + crow;
+            lx[0] = lx[1] = lx[2] = (VT)0;
+            li[0] = li[1] = 0.0;
+            if (do_load && xin && pL >= 0 && pL < ni && ccv) {
+                const VT* irow = xin + (size_t)pL * nj + cqg;
+                lx[0] = irow[0]; lx[1] = irow[npts]; lx[2] = irow[2 * npts];
+            }
+            if (Pol::kHasImage) {
+                const int fr = pL + 1;
+                if (do_load && fr >= 0 && fr <= ni + 1) {
+                    const double* frow = img + (size_t)fr * pol.Nj;
+                    if (iv0) li[0] = frow[fc0];
+                    if (iv1) li[1] = frow[fc1];
+                }
+            }
+        } else {
+            // (1) write-out of the rows that became final: relative rows e-10, e-9
+            {
+                const int rrA = e - 10, rrB = e - 9, pA = g.p0 + rrA, pB = g.p0 + rrB;
+                const bool okA = rrA >= 0 && rrA < TI && pA >= 0 && pA < ni;
+                const bool okB = rrB >= 0 && rrB < TI && pB >= 0 && pB < ni;
+                if (okA || okB) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const bool rowok = m_rs[k] ? okB : okA;
-                    if (m_st[k] && rowok) {
-                        const int slot = m_rs[k] ? slotB : slotA;
-                        const size_t prow = (size_t)(m_rs[k] ? pB : pA) * nj;
-                        xout[prow + m_g[k]] = xs[slot * 3 * W + m_lds[k]];
+                    for (int k = 0; k < 3; ++k) {
+                        const bool rowok = m_rs[k] ? okB : okA;
+                        if (m_st[k] && rowok) {
+                            const int slot = m_rs[k] ? slotB : slotA;
+                            const size_t prow = (size_t)(m_rs[k] ? pB : pA) * nj;
+                            xout[prow + m_g[k]] = xs[slot * 3 * W + m_lds[k]];
+                        }
                     }
                 }
             }
-        }
-        // (2) global loads of relative rows e+2, e+3 into registers
-        VT lx[3];
-        double li[KIMG];
-        const bool do_load = (e + 2 <= TI + 1);
-        {
-            const int pA = g.p0 + e + 2, pB = pA + 1;
-            const bool okA = do_load && xin && pA >= 0 && pA < ni, okB = do_load && xin && pB >= 0 && pB < ni;
+            // (2) global loads of relative rows e+2, e+3 into registers
+            {
+                const int pA = g.p0 + e + 2, pB = pA + 1;
+                const bool okA = do_load && xin && pA >= 0 && pA < ni, okB = do_load && xin && pB >= 0 && pB < ni;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lx[k] = (VT)0;
-                const bool rowok = m_rs[k] ? okB : okA;
-                if (m_ld[k] && rowok) lx[k] = xin[(size_t)(m_rs[k] ? pB : pA) * nj + m_g[k]];
-            }
-            if (Pol::kHasImage) {
-                const int fA = pA + 1, fB = pB + 1;   // full-image rows
-                const bool iokA = do_load && fA >= 0 && fA <= ni + 1, iokB = do_load && fB >= 0 && fB <= ni + 1;
+                for (int k = 0; k < 3; ++k) {
+                    lx[k] = (VT)0;
+                    const bool rowok = m_rs[k] ? okB : okA;
+                    if (m_ld[k] && rowok) lx[k] = xin[(size_t)(m_rs[k] ? pB : pA) * nj + m_g[k]];
+                }
+                if (Pol::kHasImage) {
+                    const int fA = pA + 1, fB = pB + 1;   // full-image rows
+                    const bool iokA = do_load && fA >= 0 && fA <= ni + 1, iokB = do_load && fB >= 0 && fB <= ni + 1;
 #pragma unroll
-                for (int k = 0; k < KIMG; ++k) {
-                    li[k] = 0.0;
-                    const bool rowok = i_rs[k] ? iokB : iokA;
-                    if (i_ok[k] && rowok) li[k] = img[(size_t)(i_rs[k] ? fB : fA) * pol.Nj + i_fc[k]];
+                    for (int k = 0; k < KIMG; ++k) {
+                        li[k] = 0.0;
+                        const bool rowok = i_rs[k] ? iokB : iokA;
+                        if (i_ok[k] && rowok) li[k] = img[(size_t)(i_rs[k] ? fB : fA) * pol.Nj + i_fc[k]];
+                    }
                 }
             }
         }
@@ -1195,7 +1246,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
         {
             const int rr = e + stage_row_off, p = g.p0 + rr;
             if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
-                const SweepRows rw = sweep_rows<G>(g, rr, (size_t)L.hj, L.sub);
+                const SweepRows rw = sweep_rows<G>(g, rr, slotA, stage_row_off, (size_t)L.hj, L.sub);
                 double u, w, gm;
                 pol.template update<G, VT>(cc, rw, xs, im, pair, cf, b0, b1, b2, u, w, gm);
                 VT* row = xs + rw.pC + cc.cC;
@@ -1204,13 +1255,23 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
         }
         // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
         if (do_load) {
+            if (ROWMAP) {
+                const int slotR = crow ? slotB : slotA;
+                VT* lrow = xs + slotR * 3 * W + clds;
+                lrow[0] = lx[0]; lrow[W] = lx[1]; lrow[2 * W] = lx[2];
+                if (Pol::kHasImage) {
+                    im[slotR * IW + ilds0] = li[0];
+                    if (ccol < 2) im[slotR * IW + ilds1] = li[1];
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (m_lds[k] >= 0) xs[(m_rs[k] ? slotB : slotA) * 3 * W + m_lds[k]] = lx[k];
-            if (Pol::kHasImage) {
+                for (int k = 0; k < 3; ++k)
+                    if (m_lds[k] >= 0) xs[(m_rs[k] ? slotB : slotA) * 3 * W + m_lds[k]] = lx[k];
+                if (Pol::kHasImage) {
 #pragma unroll
-                for (int k = 0; k < KIMG; ++k)
-                    if (i_lds[k] >= 0) im[(i_rs[k] ? slotB : slotA) * IW + i_lds[k]] = li[k];
+                    for (int k = 0; k < KIMG; ++k)
+                        if (i_lds[k] >= 0) im[(i_rs[k] ? slotB : slotA) * IW + i_lds[k]] = li[k];
+                }
             }
         }
         // (6) coefficient prefetch for the next step's point (stored float stencils)
