@@ -401,7 +401,7 @@ int build_hierarchy(vof_ctx* c, int np) {
     int nl = (int)c->L.size();
     for (int l = 0; l + 1 < nl; ++l) {
         Level &f = c->L[l], &k = c->L[l + 1];
-        dim3 g = grid2d(k.ni, k.nj, np * 9);
+        dim3 g = grid2d(k.ni, k.nj, np);
         if (l == 0) {
             Prof p(c, VOF_K_GALERKIN0, 0);
             if (c->hierarchy_float)

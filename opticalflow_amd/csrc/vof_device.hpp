@@ -418,9 +418,12 @@ __global__ __launch_bounds__(NT) void k_prolong_add(VT* __restrict__ fine, int n
 }
 
 // ------------------------------------------------------------------------------------------
-// Galerkin coarse operator A_c = R A P, one thread per (coarse point C, coarse neighbour D = C + (a,b)):
+// Galerkin coarse operator A_c = R A P, one thread per coarse point C, all 9 coarse neighbours D = C + (a,b):
 //   A_c(C, D) = 1/4 sum_f sum_g w(f, C) A(f, g) w(g, D),  f in 2C + {-1,0,1}^2, g in f + {-1,0,1}^2.
-// LEVEL0: A(f, g) is computed on the fly from the image; otherwise it is read from the stored stencil.
+// Every fine block A(f, g) is fetched (LEVEL0: computed from the image) once per thread and scattered to the
+// <= 4 coarse neighbours whose prolongation column contains g; the 81 x 9 accumulators live in registers (all
+// loops are fully unrolled, so their indices are compile-time).  With the colour-split plane layout the lanes
+// of a wave (consecutive coarse columns) read consecutive elements of one fine colour sub-plane.
 // ------------------------------------------------------------------------------------------
 template <typename CTF, typename CTC, bool LEVEL0>
 __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ frames, size_t frame_stride, int Nj,
@@ -428,55 +431,72 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
                                                  const CTF* __restrict__ Cf, int nfi, int nfj,
                                                  CTC* __restrict__ Cc, int nci, int ncj) {
     int cq = blockIdx.x * BX + threadIdx.x, cp = blockIdx.y * BY + threadIdx.y;
-    int pair = blockIdx.z / 9, off = blockIdx.z % 9;
+    int pair = blockIdx.z;
     if (cp >= nci || cq >= ncj) return;
-    int a = off / 3 - 1, b = off % 3 - 1;
-    int Dp = cp + a, Dq = cq + b;
     const CLay Lf(nfi, nfj), Lc(nci, ncj);
     const size_t nf = Lf.plane, nc = Lc.plane;
-    double acc[9];
+    double acc[9][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.0;
-    if (Dp >= 0 && Dp < nci && Dq >= 0 && Dq < ncj) {
-        for (int fi = -1; fi <= 1; ++fi) {
-            int fp = 2 * cp + fi;
-            if (fp < 0 || fp >= nfi) continue;
-            double wfi = pweight(fp, cp, nci);
-            for (int fj = -1; fj <= 1; ++fj) {
-                int fq = 2 * cq + fj;
-                if (fq < 0 || fq >= nfj) continue;
-                double wf = wfi * pweight(fq, cq, ncj);
-                PixCoef k;
-                if (LEVEL0) k = pix_coef(frames + (size_t)pair * frame_stride, Nj, fp, fq, quirks);
-                for (int oi = -1; oi <= 1; ++oi) {
-                    int gp = fp + oi;
-                    if (gp < 0 || gp >= nfi) continue;
-                    double wgi = pweight(gp, Dp, nci);
-                    if (wgi == 0.0) continue;
-                    for (int oj = -1; oj <= 1; ++oj) {
-                        int gq = fq + oj;
-                        if (gq < 0 || gq >= nfj) continue;
-                        double w = wf * wgi * pweight(gq, Dq, ncj);
-                        if (w == 0.0) continue;
-                        if (LEVEL0) {
-                            double blk[9];
-                            folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk);
+    for (int d = 0; d < 9; ++d)
 #pragma unroll
-                            for (int t = 0; t < 9; ++t) acc[t] += w * blk[t];
-                        } else {
-                            const CTF* cb = Cf + (size_t)pair * 81 * nf + (size_t)(((oi + 1) * 3 + (oj + 1)) * 9) * nf +
-                                            Lf.idx(fp, fq);
+        for (int t = 0; t < 9; ++t) acc[d][t] = 0.0;
 #pragma unroll
-                            for (int t = 0; t < 9; ++t) acc[t] += w * (double)cb[(size_t)t * nf];
+    for (int fi = -1; fi <= 1; ++fi) {
+        const int fp = 2 * cp + fi;
+        if (fp < 0 || fp >= nfi) continue;
+        const double wfi = pweight(fp, cp, nci);
+#pragma unroll
+        for (int fj = -1; fj <= 1; ++fj) {
+            const int fq = 2 * cq + fj;
+            if (fq < 0 || fq >= nfj) continue;
+            const double wf = wfi * pweight(fq, cq, ncj);
+            PixCoef k;
+            if (LEVEL0) k = pix_coef(frames + (size_t)pair * frame_stride, Nj, fp, fq, quirks);
+            const CTF* fb = LEVEL0 ? nullptr : Cf + (size_t)pair * 81 * nf + Lf.idx(fp, fq);
+#pragma unroll
+            for (int oi = -1; oi <= 1; ++oi) {
+                const int gp = fp + oi;
+                if (gp < 0 || gp >= nfi) continue;
+#pragma unroll
+                for (int oj = -1; oj <= 1; ++oj) {
+                    const int gq = fq + oj;
+                    if (gq < 0 || gq >= nfj) continue;
+                    double blk[9];
+                    if (LEVEL0) {
+                        folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk);
+                    } else {
+                        const CTF* cb = fb + (size_t)(((oi + 1) * 3 + (oj + 1)) * 9) * nf;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) blk[t] = (double)cb[(size_t)t * nf];
+                    }
+#pragma unroll
+                    for (int a = -1; a <= 1; ++a) {
+                        // g - 2 D = (fi + oi) - 2 a must be in {-1, 0, 1}: decided at compile time
+                        const int ti = fi + oi - 2 * a;
+                        if (ti < -1 || ti > 1) continue;
+                        const int Dp = cp + a;
+                        if (Dp < 0 || Dp >= nci) continue;
+                        const double wgi = pweight(gp, Dp, nci);
+#pragma unroll
+                        for (int b = -1; b <= 1; ++b) {
+                            const int tj = fj + oj - 2 * b;
+                            if (tj < -1 || tj > 1) continue;
+                            const int Dq = cq + b;
+                            if (Dq < 0 || Dq >= ncj) continue;
+                            const double w = wf * wgi * pweight(gq, Dq, ncj);
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) acc[(a + 1) * 3 + (b + 1)][t] += w * blk[t];
                         }
                     }
                 }
             }
         }
     }
-    CTC* out = Cc + (size_t)pair * 81 * nc + (size_t)(off * 9) * nc + Lc.idx(cp, cq);
+    CTC* out = Cc + (size_t)pair * 81 * nc + Lc.idx(cp, cq);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) out[(size_t)t * nc] = (CTC)(0.25 * acc[t]);
+    for (int d = 0; d < 9; ++d)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[(size_t)(d * 9 + t) * nc] = (CTC)(0.25 * acc[d][t]);
 }
 
 // ------------------------------------------------------------------------------------------
