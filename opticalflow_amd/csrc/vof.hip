@@ -50,7 +50,8 @@ struct vof_ctx {
     int Ni = 0, Nj = 0, B = 0;
     std::vector<Level> L;
     double *kx = nullptr, *kb = nullptr, *kr = nullptr, *krh = nullptr, *kp = nullptr, *kv = nullptr, *kt = nullptr;
-    double* ky = nullptr;   // V-cycle output y / z (V-typed: float when vfloat)
+    double* ky = nullptr;   // V-cycle outputs y = M p and z = M s (V-typed: float when vfloat)
+    double* kz = nullptr;
     double* b32 = nullptr;  // V-typed copy of the V-cycle right-hand side (p or s) when vfloat
     bool vfloat = false;    // V-cycle vectors stored as float32 (arithmetic stays FP64)
     double* partials = nullptr;
@@ -524,25 +525,27 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         if (nact == 0) break;
         c->cur_units = nact;
         const int* act = c->active;
-        { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kr, nullptr, nullptr, len, c->partials, act); }
-        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_RHO><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
         void* vrhs_s = c->vfloat ? (void*)c->b32 : (void*)c->kr;
-        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));
+        const double vsz = c->vfloat ? 4.0 : 8.0;
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));   // p = r + beta (p - omega v)
           VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
-        vcycle(c, c->ky, vrhs_p, np, act);                         // y = M p
+        vcycle(c, c->ky, vrhs_p, np, act);                             // y = M p
         int nb1 = krylov_apply(c, c->ky, c->kv, np, act, c->krh, 0);   // v = A y, fused (r^, v)
         if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, nb1, c->active, P.rtol, P.max_iterations); }
-        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5 + (c->vfloat ? 8.0 : 8.0) * len);
-          VDISPATCH(c, (k_update_s<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, c->kr, c->kv, len, c->sc, c->partials, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 3 + (c->vfloat ? 4.0 * len : 0.0));   // s = r - alpha v, (s, s)
+          VDISPATCH(c, (k_update_s<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kv, len, c->sc, c->partials, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_S><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
-        vcycle(c, c->ky, vrhs_s, np, act);                         // z = M s
-        int nb2 = krylov_apply(c, c->ky, c->kt, np, act, c->kr, 1);    // t = A z, fused (t, s) and (t, t)
+        { Prof p(c, VOF_K_VECTOR, 0);                                  // pairs done at the half step: x += alpha y
+          VDISPATCH(c, (k_fix_half<VT><<<dim3(64, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, len, c->sc)));
+          k_clear_half<<<(np + 255) / 256, 256, 0, s>>>(c->sc, np); }
+        vcycle(c, c->kz, vrhs_s, np, act);                             // z = M s
+        int nb2 = krylov_apply(c, c->kz, c->kt, np, act, c->kr, 1);    // t = A z, fused (t, s) and (t, t)
         if (!nb2) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); nb2 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, nb2, c->active, P.rtol, P.max_iterations); }
-        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5 + (c->vfloat ? 4.0 : 8.0) * len);
-          VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, c->kr, c->kt, len, c->sc, c->partials, act))); }
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 6 + 2.0 * vsz * len);   // x += alpha y + omega z; r = s - omega t; (r,r), (r^,r)
+          VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, (const VT*)c->kz, c->kr, c->kt, c->krh, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
     // independent residual (OF.py:1150-1151)
@@ -624,7 +627,7 @@ size_t vof_query_workspace(int n_i, int n_j, int B) {
     std::vector<std::pair<size_t, size_t>> lv{{ni, nj}};
     while (std::max(lv.back().first, lv.back().second) > (size_t)COARSEST_MAX)
         lv.push_back({(lv.back().first + 1) / 2, (lv.back().second + 1) / 2});
-    total += 9 * b * 3 * ni * nj;
+    total += 10 * b * 3 * ni * nj;
     for (size_t l = 0; l < lv.size(); ++l) {
         size_t npts = lv[l].first * lv[l].second;
         if (l + 1 < lv.size()) total += 2 * b * 3 * npts;
@@ -697,7 +700,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     int nl = (int)c->L.size();
     if (nl > 16) { c->err = "too many levels"; return -1; }
     size_t len0 = 3 * l0.npts;
-    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky, &c->b32})
+    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky, &c->kz, &c->b32})
         if (int rc = dev_alloc(c, v, (size_t)B * len0)) return rc;
     for (int l = 0; l < nl; ++l) {
         Level& lv = c->L[l];

@@ -27,7 +27,7 @@ struct PairScalars {
     int iterations;
     int converged;
     int breakdown;
-    int pad;
+    int halfstep;     // 1: converged at the half step, x += alpha y still pending; 2: done
 };
 
 __device__ __forceinline__ int fold(int t, int n) { return t < 0 ? 1 : (t >= n ? n - 2 : t); }
@@ -650,6 +650,12 @@ __global__ __launch_bounds__(RBLK) void k_dot2(const double* __restrict__ a1, co
     block_store_partials(s0, s1, 0.0, partials, a2 ? 2 : 1, gridDim.x, pair, blockIdx.x);
 }
 
+// The BiCGStab vector updates process two elements per lane and iteration (16-B accesses on the float64
+// vectors) when the vector length is even; `len2` = len / 2 (or 0 to force the scalar path).
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { typedef double2 type; };
+template <> struct Vec2<float> { typedef float2 type; };
+
 // p = r + beta (p - omega v); optionally also a VT copy of p (the V-cycle's right-hand side)
 template <typename VT>
 __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const double* __restrict__ r,
@@ -660,18 +666,32 @@ __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const
     if (!active[pair]) return;
     double beta = sc[pair].beta, omega = sc[pair].omega;
     size_t off = (size_t)pair * len;
-    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK)
-    {
+    if ((len & 1) == 0) {
+        typedef typename Vec2<VT>::type V2;
+        double2* p2 = reinterpret_cast<double2*>(p + off);
+        const double2* r2 = reinterpret_cast<const double2*>(r + off);
+        const double2* v2 = reinterpret_cast<const double2*>(v + off);
+        V2* c2 = pcopy ? reinterpret_cast<V2*>(pcopy + off) : nullptr;
+        for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len / 2; i += (size_t)gridDim.x * RBLK) {
+            double2 a = p2[i], rr = r2[i], vv = v2[i];
+            a.x = rr.x + beta * (a.x - omega * vv.x);
+            a.y = rr.y + beta * (a.y - omega * vv.y);
+            p2[i] = a;
+            if (c2) { V2 t; t.x = (VT)a.x; t.y = (VT)a.y; c2[i] = t; }
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
         double t = r[off + i] + beta * (p[off + i] - omega * v[off + i]);
         p[off + i] = t;
         if (pcopy) pcopy[off + i] = (VT)t;
     }
 }
 
-// x += alpha y ; r -= alpha v (r becomes s) ; partial (s, s); optionally a VT copy of s
+// r -= alpha v (r becomes s) ; partial (s, s); optionally a VT copy of s.  (x is updated once per iteration, in
+// k_update_xr; a pair that converges at this half step gets its x += alpha y from k_fix_half.)
 template <typename VT>
-__global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ x, const VT* __restrict__ y,
-                                                   double* __restrict__ r, const double* __restrict__ v, size_t len,
+__global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ r, const double* __restrict__ v, size_t len,
                                                    const PairScalars* __restrict__ sc, double* __restrict__ partials,
                                                    const int* __restrict__ active, VT* __restrict__ scopy) {
     int pair = blockIdx.y;
@@ -679,34 +699,88 @@ __global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ x, const
     double alpha = sc[pair].alpha;
     size_t off = (size_t)pair * len;
     double ss = 0;
-    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
-        x[off + i] += alpha * (double)y[off + i];
-        double s = r[off + i] - alpha * v[off + i];
-        r[off + i] = s;
-        if (scopy) scopy[off + i] = (VT)s;
-        ss += s * s;
+    if ((len & 1) == 0) {
+        typedef typename Vec2<VT>::type V2;
+        double2* r2 = reinterpret_cast<double2*>(r + off);
+        const double2* v2 = reinterpret_cast<const double2*>(v + off);
+        V2* c2 = scopy ? reinterpret_cast<V2*>(scopy + off) : nullptr;
+        for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len / 2; i += (size_t)gridDim.x * RBLK) {
+            double2 a = r2[i], vv = v2[i];
+            a.x -= alpha * vv.x;
+            a.y -= alpha * vv.y;
+            r2[i] = a;
+            if (c2) { V2 t; t.x = (VT)a.x; t.y = (VT)a.y; c2[i] = t; }
+            ss += a.x * a.x + a.y * a.y;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+            double s = r[off + i] - alpha * v[off + i];
+            r[off + i] = s;
+            if (scopy) scopy[off + i] = (VT)s;
+            ss += s * s;
+        }
     }
     block_store_partials(ss, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
 }
 
-// x += omega z ; r = s - omega t ; partial (r, r)
+// x += alpha y + omega z ; r = s - omega t ; partials: slot 0 = (r, r), slot 1 = (r^, r) (the next iteration's rho)
 template <typename VT>
-__global__ __launch_bounds__(RBLK) void k_update_xr(double* __restrict__ x, const VT* __restrict__ z,
-                                                    double* __restrict__ r, const double* __restrict__ t, size_t len,
-                                                    const PairScalars* __restrict__ sc, double* __restrict__ partials,
-                                                    const int* __restrict__ active) {
+__global__ __launch_bounds__(RBLK) void k_update_xr(double* __restrict__ x, const VT* __restrict__ y,
+                                                    const VT* __restrict__ z, double* __restrict__ r,
+                                                    const double* __restrict__ t, const double* __restrict__ rh,
+                                                    size_t len, const PairScalars* __restrict__ sc,
+                                                    double* __restrict__ partials, const int* __restrict__ active) {
     int pair = blockIdx.y;
     if (!active[pair]) return;
-    double omega = sc[pair].omega;
+    double alpha = sc[pair].alpha, omega = sc[pair].omega;
     size_t off = (size_t)pair * len;
-    double rr = 0;
-    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
-        x[off + i] += omega * (double)z[off + i];
-        double s = r[off + i] - omega * t[off + i];
-        r[off + i] = s;
-        rr += s * s;
+    double rr = 0, rho = 0;
+    if ((len & 1) == 0) {
+        typedef typename Vec2<VT>::type V2;
+        double2* x2 = reinterpret_cast<double2*>(x + off);
+        double2* r2 = reinterpret_cast<double2*>(r + off);
+        const double2* t2 = reinterpret_cast<const double2*>(t + off);
+        const double2* h2 = reinterpret_cast<const double2*>(rh + off);
+        const V2* y2 = reinterpret_cast<const V2*>(y + off);
+        const V2* z2 = reinterpret_cast<const V2*>(z + off);
+        for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len / 2; i += (size_t)gridDim.x * RBLK) {
+            double2 xx = x2[i], a = r2[i], tt = t2[i], hh = h2[i];
+            V2 yy = y2[i], zz = z2[i];
+            xx.x += alpha * (double)yy.x + omega * (double)zz.x;
+            xx.y += alpha * (double)yy.y + omega * (double)zz.y;
+            x2[i] = xx;
+            a.x -= omega * tt.x;
+            a.y -= omega * tt.y;
+            r2[i] = a;
+            rr += a.x * a.x + a.y * a.y;
+            rho += hh.x * a.x + hh.y * a.y;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+            x[off + i] += alpha * (double)y[off + i] + omega * (double)z[off + i];
+            double s = r[off + i] - omega * t[off + i];
+            r[off + i] = s;
+            rr += s * s;
+            rho += rh[off + i] * s;
+        }
     }
-    block_store_partials(rr, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
+    block_store_partials(rr, rho, 0.0, partials, 2, gridDim.x, pair, blockIdx.x);
+}
+
+// x += alpha y for the pairs that met the stopping rule at the half step (flagged by k_scalar<S_S>)
+template <typename VT>
+__global__ __launch_bounds__(RBLK) void k_fix_half(double* __restrict__ x, const VT* __restrict__ y, size_t len,
+                                                   PairScalars* __restrict__ sc) {
+    int pair = blockIdx.y;
+    if (sc[pair].halfstep != 1) return;
+    double alpha = sc[pair].alpha;
+    size_t off = (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK)
+        x[off + i] += alpha * (double)y[off + i];
+}
+__global__ void k_clear_half(PairScalars* __restrict__ sc, int np) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < np && sc[k].halfstep == 1) sc[k].halfstep = 2;
 }
 
 __global__ void k_fill(double* __restrict__ x, size_t npts, double c0, double c1, double c2) {
@@ -722,7 +796,7 @@ __global__ void k_convert(const TA* __restrict__ a, TB* __restrict__ b, size_t n
         b[i] = (TB)a[i];
 }
 
-enum ScalarStep { S_BNORM = 0, S_R0, S_RHO, S_ALPHA, S_S, S_OMEGA, S_R, S_FINAL };
+enum ScalarStep { S_BNORM = 0, S_R0, S_ALPHA, S_S, S_OMEGA, S_R, S_FINAL };
 
 __device__ __forceinline__ double sum_partials(const double* __restrict__ pp, int nblk) {
     double s = 0;
@@ -738,7 +812,7 @@ __global__ void k_scalar(PairScalars* __restrict__ sc, const double* __restrict_
     if (STEP != S_BNORM && STEP != S_FINAL && !active[pair]) return;
     const double* pp = partials + (size_t)pair * 3 * nblk;
     double a = sum_partials(pp, nblk);
-    double b = (STEP == S_OMEGA) ? sum_partials(pp + nblk, nblk) : 0.0;
+    double b = (STEP == S_OMEGA || STEP == S_R) ? sum_partials(pp + nblk, nblk) : 0.0;
     if (threadIdx.x != 0) return;
     PairScalars& s = sc[pair];
     if (STEP == S_BNORM) {
@@ -749,25 +823,26 @@ __global__ void k_scalar(PairScalars* __restrict__ sc, const double* __restrict_
         s.iterations = 0;
         s.converged = 0;
         s.breakdown = 0;
+        s.halfstep = 0;
         active[pair] = 1;
     } else if (STEP == S_R0) {
         s.rnorm2 = a;
         if (a <= s.tol2) { s.converged = 1; active[pair] = 0; }
         if (max_it <= 0) active[pair] = 0;
-    } else if (STEP == S_RHO) {
-        double beta = (a / s.rho) * (s.alpha / s.omega);
-        if (!(fabs(a) > 0.0) || !isfinite(beta)) { s.breakdown = 1; active[pair] = 0; return; }
-        s.beta = beta;
+        // r^ = r0, so rho_1 = (r^, r0) = ||r0||^2; with rho_0 = alpha = omega = 1: beta = rho_1 (p = v = 0 anyway)
+        s.beta = a;
         s.rho = a;
+        if (!(a > 0.0) && active[pair]) { s.breakdown = 1; active[pair] = 0; }
     } else if (STEP == S_ALPHA) {
         double alpha = s.rho / a;
         if (!isfinite(alpha)) { s.breakdown = 1; active[pair] = 0; s.alpha = 0.0; return; }
         s.alpha = alpha;
     } else if (STEP == S_S) {
-        if (a <= s.tol2) {  // converged at the half step: x already holds x + alpha y
+        if (a <= s.tol2) {  // converged at the half step: k_fix_half adds the pending alpha y to x
             s.rnorm2 = a;
             s.iterations += 1;
             s.converged = 1;
+            s.halfstep = 1;
             active[pair] = 0;
         }
     } else if (STEP == S_OMEGA) {
@@ -779,6 +854,11 @@ __global__ void k_scalar(PairScalars* __restrict__ sc, const double* __restrict_
         s.iterations += 1;
         if (a <= s.tol2) { s.converged = 1; active[pair] = 0; }
         else if (s.breakdown || s.iterations >= max_it || !isfinite(a)) active[pair] = 0;
+        else {   // next iteration's rho = (r^, r) came with the same reduction
+            double beta = (b / s.rho) * (s.alpha / s.omega);
+            if (!(fabs(b) > 0.0) || !isfinite(beta)) { s.breakdown = 1; active[pair] = 0; }
+            else { s.beta = beta; s.rho = b; }
+        }
     } else if (STEP == S_FINAL) {
         s.rnorm2 = a;  // independent ||b - A x||^2 (OF.py:1151)
     }
