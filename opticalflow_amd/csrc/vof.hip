@@ -78,6 +78,7 @@ struct vof_ctx {
     bool hierarchy_float = false;
     bool fused = true;   // fused streaming 4-colour sweeps (false: one launch per colour)
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
+    bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     // profiler
     bool prof = false;
@@ -296,6 +297,19 @@ void restrict_level_t(vof_ctx* c, int l, const VT* fine, VT* coarse, int np, con
     k_restrict<VT><<<grid2d(k.ni, k.nj, np), blk2d, 0, c->stream>>>(fine, f.ni, f.nj, coarse, k.ni, k.nj, active);
 }
 
+// level 0, matrix-free: coarse right-hand side b_1 = R (b - A x) in one pass (no fine residual in HBM)
+template <typename VT>
+void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, VT* bc, int np, const int* active) {
+    Level &f = c->L[0], &k = c->L[1];
+    int nbands = (f.ni + 127) / 128;
+    int TI = std::max(2, (((f.ni + nbands - 1) / nbands + 1) / 2) * 2);
+    dim3 g((k.nj + RR_CO - 1) / RR_CO, (k.ni + TI / 2 - 1) / (TI / 2), np);
+    Prof p(c, VOF_K_APPLY0, 0, (8.0 + 6.0 * sizeof(VT)) * f.npts + 3.0 * sizeof(VT) * k.npts);
+    k_stream_resrestrict0<VT, VT, VT><<<g, AP_THREADS, 0, c->stream>>>(
+        c->frames, frame_stride(c), c->Nj, f.ni, f.nj, TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
+        c->prm.reference_quirks, x, b, bc, k.ni, k.nj, active);
+}
+
 template <typename VT>
 void prolong_add_level_t(vof_ctx* c, int l, VT* fine, const VT* coarse, int np, const int* active) {
     Level &f = c->L[l], &k = c->L[l + 1];
@@ -384,8 +398,12 @@ void vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) 
     const int nu1 = (l > 0 && c->prm.nu_pre_coarse > 0) ? c->prm.nu_pre_coarse : c->prm.nu_pre;
     const int nu2 = (l > 0 && c->prm.nu_post_coarse > 0) ? c->prm.nu_post_coarse : c->prm.nu_post;
     smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu1, true, false, np, active);
-    apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
-    restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
+    if (l == 0 && lv.C == nullptr && c->stream_apply && c->fuse_restrict) {
+        resrestrict_fine_t<VT>(c, x, b, (VT*)nx.b, np, active);
+    } else {
+        apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
+        restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
+    }
     vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
     prolong_add_level_t<VT>(c, l, x, (const VT*)nx.x, np, active);
     smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active);
@@ -690,6 +708,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
         c->geo_b_stored = e[0] && e[1] == 'B';
     }
     if (const char* e = getenv("VOF_STREAM_APPLY")) c->stream_apply = e[0] != '0';
+    if (const char* e = getenv("VOF_FUSE_RESTRICT")) c->fuse_restrict = e[0] != '0';
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
     c->L.push_back(l0);

@@ -1528,4 +1528,151 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
     }
 }
 
+// ==========================================================================================
+// k_stream_resrestrict0: coarse right-hand side  b_c = R (b - A x)  of level 0 in one pass: the fine residual
+// rows are produced exactly as in k_stream_apply0<1> but kept in a small LDS ring and immediately restricted
+// (full weighting, R = P^T / 4), so the fine residual is never written to / re-read from HBM
+// (I + x(3) + b(3) in, 3/4 out per fine pixel = 62 B instead of 80 + 30).
+// A block owns 63 coarse columns x TI/2 coarse rows: fine columns [126 bx - 1, 126 bx + 127), fine rows
+// [p0 - 1, p0 + TI) with p0 = by * TI (even).
+// ==========================================================================================
+constexpr int RR_CO = 63;   // coarse columns per strip (fine stride 126)
+
+template <typename XT, typename BT, typename CT2>
+__global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
+    const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj, int TI, double alpha, double beta,
+    int quirks, const XT* __restrict__ x, const BT* __restrict__ b, CT2* __restrict__ bc, int nci, int ncj,
+    const int* __restrict__ active) {
+    __shared__ XT xs[AP_RING * 3 * AP_W];
+    __shared__ double im[AP_RING * AP_W];
+    __shared__ double rs[AP_RING * 3 * 128];     // residual ring [row][field][fine column of the strip]
+    const int pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    const int tid = threadIdx.x;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int col = tid & 127;
+    const int q0 = blockIdx.x * (2 * RR_CO) - 1;        // first fine column whose residual the strip computes
+    const int p0 = blockIdx.y * TI - 1;                 // first fine row
+    const int q = q0 + col;
+    const bool col_ok = q >= 0 && q < nj;
+    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const XT* xp = x + off;
+    const double* img = frames + (size_t)pair * frame_stride;
+    const bool oL = q - 1 < 0, oR = q + 1 >= nj;
+    const int cC = col + 1, cL = oL ? col + 2 : col, cR = oR ? col : col + 2;
+    // restriction phase: thread <-> (field, coarse column of the strip)
+    const int ef = tid / RR_CO, em = tid % RR_CO;
+    const int ecq = blockIdx.x * RR_CO + em;
+    const bool e_on = tid < 3 * RR_CO && ecq < ncj;
+    const size_t ncpts = (size_t)nci * ncj;
+    const int nsteps = TI / 2 + 1;                      // fine rows p0 .. p0 + TI (relative 0 .. TI)
+    for (int s = -2; s <= nsteps + 1; ++s) {
+        const int r = 2 * s;
+        // ---- restriction of coarse row k = s - 2 (fine relative rows 2k, 2k+1, 2k+2), computed in earlier steps
+        {
+            const int k = s - 2;
+            const int cp = blockIdx.y * (TI / 2) + k;
+            if (k >= 0 && k < TI / 2 && cp < nci && e_on) {
+                double acc = 0.0;
+#pragma unroll
+                for (int di = -1; di <= 1; ++di) {
+                    const int fp = 2 * cp + di;
+                    if (fp < 0 || fp >= ni) continue;
+                    const double wi = pweight(fp, cp, nci);
+                    const double* row = rs + (((2 * k + 1 + di) & (AP_RING - 1)) * 3 + ef) * 128;
+#pragma unroll
+                    for (int dj = -1; dj <= 1; ++dj) {
+                        const int fq = 2 * ecq + dj;
+                        if (fq < 0 || fq >= nj) continue;
+                        acc += wi * pweight(fq, ecq, ncj) * row[2 * em + 1 + dj];
+                    }
+                }
+                bc[(size_t)pair * 3 * ncpts + (size_t)ef * ncpts + (size_t)cp * ncj + ecq] = (CT2)(0.25 * acc);
+            }
+        }
+        // ---- global loads of relative row r + 3 + half into registers
+        const int rl = r + 3 + half, pl = p0 + rl;
+        const bool need = rl <= TI + 1;
+        const bool row_ld = need && pl >= 0 && pl < ni;
+        const bool irow_ld = need && pl + 1 >= 0 && pl + 1 <= ni + 1;
+        XT l0 = (XT)0, l1 = (XT)0, l2 = (XT)0, h0 = (XT)0, h1 = (XT)0, h2 = (XT)0;
+        double li0 = 0.0, li1 = 0.0;
+        if (row_ld) {
+            const XT* xr = xp + (size_t)pl * nj;
+            if (col_ok) { l0 = xr[q]; l1 = xr[npts + q]; l2 = xr[2 * npts + q]; }
+            const int qh = (col == 0) ? q0 - 1 : q0 + 128;
+            if ((col == 0 || col == 127) && qh >= 0 && qh < nj) { h0 = xr[qh]; h1 = xr[npts + qh]; h2 = xr[2 * npts + qh]; }
+        }
+        if (irow_ld) {
+            const double* ir = img + (size_t)(pl + 1) * Nj;
+            const int fc0 = q0 + col, fc1 = q0 + 128 + col;
+            if (fc0 >= 0 && fc0 <= nj + 1) li0 = ir[fc0];
+            if (col < 2 && fc1 >= 0 && fc1 <= nj + 1) li1 = ir[fc1];
+        }
+        // ---- fine residual of relative row r + half -> LDS residual ring
+        const int rc = r + half, p = p0 + rc;
+        if (s >= 0 && rc <= TI) {
+            double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+            if (p >= 0 && p < ni && col_ok) {
+                const bool oU = p - 1 < 0, oD = p + 1 >= ni;
+                const int sU = ((rc - 1) + AP_RING) & (AP_RING - 1), sC = (rc + AP_RING) & (AP_RING - 1),
+                          sD = ((rc + 1) + AP_RING) & (AP_RING - 1);
+                const double* i0 = im + sU * AP_W;
+                const double* i1 = im + sC * AP_W;
+                const double* i2 = im + sD * AP_W;
+                double imm = i0[col], im0 = i0[col + 1], imp = i0[col + 2];
+                double i0m = i1[col], i00 = i1[col + 1], i0p = i1[col + 2];
+                double ipm = i2[col], ip0 = i2[col + 1], ipp = i2[col + 2];
+                PixCoef k;
+                k.P = i00;
+                k.Dx = (ip0 - im0) / 2;
+                k.Dy = quirks ? k.Dx : (i0p - i0m) / 2;
+                k.Dxx = ip0 + im0 - 2 * i00;
+                k.Dyy = i0p + i0m - 2 * i00;
+                k.Dxy = (ipp - ipm - imp + imm) / 4;
+                const XT* ru = xs + (oU ? sD : sU) * 3 * AP_W;
+                const XT* rcn = xs + sC * 3 * AP_W;
+                const XT* rd = xs + (oD ? sU : sD) * 3 * AP_W;
+                const double sUL = (oU && oL) ? 2.0 : 1.0, sUR = (oU && oR) ? 2.0 : 1.0;
+                const double sDL = (oD && oL) ? 2.0 : 1.0, sDR = (oD && oR) ? 2.0 : 1.0;
+                Nbr n;
+                n.u[0] = sUL * (double)ru[cL]; n.w[0] = sUL * (double)ru[AP_W + cL];
+                n.u[1] = (double)ru[cC];       n.w[1] = (double)ru[AP_W + cC];       n.g[1] = (double)ru[2 * AP_W + cC];
+                n.u[2] = sUR * (double)ru[cR]; n.w[2] = sUR * (double)ru[AP_W + cR];
+                n.u[3] = (double)rcn[cL];      n.w[3] = (double)rcn[AP_W + cL];      n.g[3] = (double)rcn[2 * AP_W + cL];
+                n.u[4] = (double)rcn[cC];      n.w[4] = (double)rcn[AP_W + cC];      n.g[4] = (double)rcn[2 * AP_W + cC];
+                n.u[5] = (double)rcn[cR];      n.w[5] = (double)rcn[AP_W + cR];      n.g[5] = (double)rcn[2 * AP_W + cR];
+                n.u[6] = sDL * (double)rd[cL]; n.w[6] = sDL * (double)rd[AP_W + cL];
+                n.u[7] = (double)rd[cC];       n.w[7] = (double)rd[AP_W + cC];       n.g[7] = (double)rd[2 * AP_W + cC];
+                n.u[8] = sDR * (double)rd[cR]; n.w[8] = sDR * (double)rd[AP_W + cR];
+                offdiag0(k, alpha, beta, n, y0, y1, y2);
+                const double P = k.P;
+                y0 += (P * (k.Dxx - 2 * P) - 4 * alpha) * n.u[4] + P * k.Dxy * n.w[4];
+                y1 += (P * (k.Dyy - 2 * P) - 4 * alpha) * n.w[4] + P * k.Dxy * n.u[4];
+                y2 += (-1 - 4 * beta) * n.g[4] + k.Dx * n.u[4] + k.Dy * n.w[4];
+                const size_t idx = (size_t)p * nj + q;
+                y0 = (double)b[off + idx] - y0;
+                y1 = (double)b[off + npts + idx] - y1;
+                y2 = (double)b[off + 2 * npts + idx] - y2;
+            }
+            double* rr = rs + ((rc & (AP_RING - 1)) * 3) * 128 + col;
+            rr[0] = y0; rr[128] = y1; rr[256] = y2;
+        }
+        // ---- loaded row -> LDS ring
+        if (need) {
+            const int sl = (rl + AP_RING) & (AP_RING - 1);
+            XT* xr = xs + sl * 3 * AP_W;
+            xr[col + 1] = l0; xr[AP_W + col + 1] = l1; xr[2 * AP_W + col + 1] = l2;
+            if (col == 0 || col == 127) {
+                const int ch = (col == 0) ? 0 : AP_OUT + 1;
+                xr[ch] = h0; xr[AP_W + ch] = h1; xr[2 * AP_W + ch] = h2;
+            }
+            double* ir = im + sl * AP_W;
+            ir[col] = li0;
+            if (col < 2) ir[128 + col] = li1;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace vof
