@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="float32", choices=["float64", "float32"])
     ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32"])
-    ap.add_argument("--nu-pre", type=int, default=2)
+    ap.add_argument("--nu-pre", type=int, default=1)
     ap.add_argument("--nu-post", type=int, default=2)
     ap.add_argument("--nu-pre-coarse", type=int, default=1)
     ap.add_argument("--nu-post-coarse", type=int, default=1)

@@ -38,7 +38,7 @@ typedef struct vof_params {
     double initial_remodelling;/* OF.py:723,802 */
     double rtol;               /* OF.py:1120: 1e-6, ||b - A x||_2 <= rtol ||b||_2 (unpreconditioned, OF.py:1126) */
     int32_t max_iterations;    /* OF.py:1120: 1000 BiCGStab iterations */
-    int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction (default 2) */
+    int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction on level 0 (default 1) */
     int32_t nu_post;           /* ... and after (default 2) */
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
     int32_t coarse_precision;  /* 1 (default): float32 storage of the Galerkin stencils; 0: float64 */

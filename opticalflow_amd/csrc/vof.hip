@@ -626,7 +626,7 @@ void vof_default_params(vof_params* p) {
     p->delta_t = 1.0;
     p->rtol = 1e-6;                // OF.py:1120
     p->max_iterations = 1000;      // OF.py:1120
-    p->nu_pre = 2;                 // V(2,2) on level 0 ...
+    p->nu_pre = 1;                 // V(1,2) on level 0 ...
     p->nu_post = 2;
     p->nu_pre_coarse = 1;          // ... V(1,1) on the stored-stencil levels (measured best time to solution)
     p->nu_post_coarse = 1;
