@@ -14,8 +14,8 @@ import numpy as np
 
 from . import _native
 
-__all__ = ["variational_optical_flow", "make_fake_data_frame", "blur_movie", "format_elapsed_time",
-           "apply_constant_boundary_condition", "choose_pairs_in_flight"]
+__all__ = ["variational_optical_flow", "vary_regularisation", "make_fake_data_frame", "blur_movie",
+           "format_elapsed_time", "apply_constant_boundary_condition", "choose_pairs_in_flight"]
 
 
 def make_fake_data_frame(x_position, y_position, sigma=1.0, width=20.0, include_noise=False, dimension=1000):
@@ -89,7 +89,8 @@ def variational_optical_flow(movie,
                              vcycle_precision="float64",
                              multigrid_sweeps=None,
                              verbose=False,
-                             return_stats=False):
+                             return_stats=False,
+                             _solver=None):
     """Variational optical flow with remodelling on an image stack, on one MI355X.
 
     Positional/keyword arguments up to ``use_direct_solver`` have the reference's meaning
@@ -138,11 +139,14 @@ def variational_optical_flow(movie,
         params.nu_pre, params.nu_post = ms[0], ms[1]
         if len(ms) == 4:
             params.nu_pre_coarse, params.nu_post_coarse = ms[2], ms[3]
-    if max_pairs_in_flight is None:
+    if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()
-    with _native.Solver(N_i, N_j, max_pairs_in_flight, device=device) as solver:
-        v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+    if _solver is not None:      # a caller-owned context (vary_regularisation re-uses one workspace for all solves)
+        v_x, v_y, remodelling, speed, stats = _solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+    else:
+        with _native.Solver(N_i, N_j, max_pairs_in_flight, device=device) as solver:
+            v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
     if verbose:
         m, s, ms = format_elapsed_time(time.time() - t0)
         print(f"Elapsed time for solve: {m} minutes, {s} seconds, {ms} milliseconds")
@@ -170,3 +174,57 @@ def variational_optical_flow(movie,
     if return_stats:
         result["stats"] = stats
     return result
+
+
+def vary_regularisation(movie,
+                        speed_alpha_values=np.arange(500, 2000, 500),
+                        remodelling_alpha_values=np.arange(500, 2000, 500),
+                        filename=None,
+                        **kwargs):
+    """Vary both regularisation parameters and keep the summary statistics for heat-maps; same arguments,
+    result dictionary and optional ``np.save`` as the reference (OF.py:1918-1998).  Every
+    ``(speed_alpha, remodelling_alpha)`` combination is an independent solve of the same movie; one device
+    workspace is created once and re-used for all of them, each solve batches all frame pairs.
+
+    Returns a dict with ``speed_alpha_values``, ``remodelling_alpha_values``, ``speed_means``,
+    ``speed_variances``, ``remodelling_means``, ``remodelling_variances``, ``converged`` and ``functional``
+    (``L1_functional + speed_functional + remodelling_functional``, OF.py:1983), each of shape
+    ``(len(speed_alpha_values), len(remodelling_alpha_values))``.
+    """
+    movie = np.asarray(movie)
+    if movie.ndim != 3:
+        raise ValueError("movie must be a 3-D array (frames, x, y)")
+    shape = (len(speed_alpha_values), len(remodelling_alpha_values))
+    speed_means = np.zeros(shape)
+    speed_variances = np.zeros_like(speed_means)
+    remodelling_means = np.zeros_like(speed_means)
+    remodelling_variances = np.zeros_like(speed_means)
+    converged = np.zeros_like(speed_means, dtype=bool)
+    total_variations = np.zeros_like(speed_means)
+    T, N_i, N_j = movie.shape
+    device = kwargs.get("device", 0)
+    pairs = kwargs.pop("max_pairs_in_flight", None) or choose_pairs_in_flight(N_i, N_j, T - 1, device)
+    with _native.Solver(N_i, N_j, pairs, device=device) as solver:
+        for i, speed_alpha in enumerate(speed_alpha_values):
+            for j, remodelling_alpha in enumerate(remodelling_alpha_values):
+                result = variational_optical_flow(movie, speed_alpha=speed_alpha, remodelling_alpha=remodelling_alpha,
+                                                  _solver=solver, **kwargs)
+                speed_means[i, j] = np.mean(result["speed"])
+                speed_variances[i, j] = np.var(result["speed"])
+                remodelling_means[i, j] = np.mean(result["remodelling"])
+                remodelling_variances[i, j] = np.var(result["remodelling"])
+                converged[i, j] = result["converged"]
+                total_variations[i, j] = (result["L1_functional"] + result["speed_functional"]
+                                          + result["remodelling_functional"])
+    result_dict = {}
+    result_dict["speed_alpha_values"] = speed_alpha_values
+    result_dict["remodelling_alpha_values"] = remodelling_alpha_values
+    result_dict["speed_means"] = speed_means
+    result_dict["speed_variances"] = speed_variances
+    result_dict["remodelling_means"] = remodelling_means
+    result_dict["remodelling_variances"] = remodelling_variances
+    result_dict["converged"] = converged
+    result_dict["functional"] = total_variations
+    if filename is not None:
+        np.save(filename, result_dict)
+    return result_dict

@@ -364,3 +364,22 @@ def relative_residual(I, J, v_x, v_y, gamma, alpha, beta, reference_quirks=True)
     A, b = assemble_system(I, J, alpha, beta, reference_quirks)
     x = np.stack([v_x, v_y, gamma], axis=-1).ravel()
     return float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
+
+
+def vary_regularisation(movie, speed_alpha_values, remodelling_alpha_values, **kwargs):
+    """Oracle restatement of OF.py:1918-1998: grid sweep over (speed_alpha, remodelling_alpha)."""
+    shape = (len(speed_alpha_values), len(remodelling_alpha_values))
+    out = {k: np.zeros(shape) for k in ("speed_means", "speed_variances", "remodelling_means",
+                                        "remodelling_variances", "functional")}
+    out["converged"] = np.zeros(shape, dtype=bool)
+    for i, a in enumerate(speed_alpha_values):
+        for j, b in enumerate(remodelling_alpha_values):
+            r = variational_optical_flow(movie, speed_alpha=a, remodelling_alpha=b, **kwargs)
+            out["speed_means"][i, j] = np.mean(r["speed"]); out["speed_variances"][i, j] = np.var(r["speed"])
+            out["remodelling_means"][i, j] = np.mean(r["remodelling"])
+            out["remodelling_variances"][i, j] = np.var(r["remodelling"])
+            out["converged"][i, j] = r["converged"]
+            out["functional"][i, j] = r["L1_functional"] + r["speed_functional"] + r["remodelling_functional"]  # OF.py:1983
+    out["speed_alpha_values"] = speed_alpha_values
+    out["remodelling_alpha_values"] = remodelling_alpha_values
+    return out

@@ -82,6 +82,12 @@ def main():
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     from oracle import vof_oracle as orc
     OF = import_reference()
+    if "--only-g9" in sys.argv:      # add the vary_regularisation fixture without touching the others
+        np_savez = np.savez
+        def _only_g9(path, *a, **k):
+            if os.path.basename(path).startswith("g9_"):
+                np_savez(path, *a, **k)
+        np.savez = _only_g9
 
     # ---- G1: the reference's only enabled experiment, AVOF.py:26-50 -------------------
     f1, dx = OF.make_fake_data_frame(x_position=2.5, y_position=2.5, sigma=3, width=5, dimension=50,
@@ -162,6 +168,20 @@ def main():
     res, _ = run_ref(OF, movie, **kw)
     np.savez(os.path.join(HERE, "g7_texture_64x3.npz"), movie=movie, v_x=res["v_x"], v_y=res["v_y"],
              remodelling=res["remodelling"], **kw_to_np(kw), **scalars(res))
+
+    # ---- G9: vary_regularisation (OF.py:1918-1998), 2x3 grid on a small stack ----------
+    movie = orc.make_texture_stack(24, 3, seed=9)
+    captured.clear()
+    scipy.sparse.linalg.spsolve = _capturing_spsolve
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            vr = OF.vary_regularisation(movie, speed_alpha_values=np.array([1.0, 5.0]),
+                                        remodelling_alpha_values=np.array([10.0, 100.0, 1000.0]), filename=None,
+                                        use_direct_solver=True, delta_x=0.5, delta_t=1.0)
+    finally:
+        scipy.sparse.linalg.spsolve = _real_spsolve
+    np.savez(os.path.join(HERE, "g9_vary_regularisation.npz"), movie=movie,
+             **{k: np.asarray(v) for k, v in vr.items() if k != "converged"})
 
     # ---- synthetic generator: make_fake_data_frame itself ------------------------------
     fr, dxx = OF.make_fake_data_frame(1.3, 2.9, sigma=1.7, width=6.0, dimension=37, include_noise=False)

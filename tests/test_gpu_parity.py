@@ -219,3 +219,17 @@ def test_float32_vcycle_storage_same_answer(of, name):
     assert res["stats"]["converged"].all()
     assert res["stats"]["relative_residual"].max() < 1e-9
     check_fields(res, g, 1e-6 if "8bit" in name else TIGHT)
+
+
+def test_vary_regularisation_against_reference_fixture(of, tmp_path):
+    """The batch caller of the hot path (OF.py:1918-1998): same dictionary, same optional np.save."""
+    g = load_golden("g9_vary_regularisation.npz")
+    fn = str(tmp_path / "sweep.npy")
+    r = of.vary_regularisation(g["movie"], speed_alpha_values=g["speed_alpha_values"],
+                               remodelling_alpha_values=g["remodelling_alpha_values"], filename=fn,
+                               delta_x=0.5, delta_t=1.0, rtol=1e-10)
+    for k in ("speed_means", "speed_variances", "remodelling_means", "remodelling_variances", "functional"):
+        np.testing.assert_allclose(r[k], g[k], rtol=2e-6, atol=1e-12, err_msg=k)
+    assert r["converged"].all() and r["converged"].dtype == bool
+    saved = np.load(fn, allow_pickle=True).item()          # our own file (the reference's scripts read it this way)
+    np.testing.assert_array_equal(saved["speed_means"], r["speed_means"])

@@ -122,3 +122,12 @@ def test_eliminated_system_reproduces_full_solution():
     np.testing.assert_allclose(orc.interior_to_full(xi), np.stack([vx, vy, gm]), rtol=1e-10, atol=1e-12)
     r = orc.apply_operator_interior(I, xi, 2.5, 7.0) - orc.rhs_interior(I, J)
     assert np.linalg.norm(r) / np.linalg.norm(orc.rhs_interior(I, J)) < 1e-10
+
+
+def test_vary_regularisation_matches_reference():
+    """OF.py:1918-1998 on a 2x3 parameter grid (fixture produced by the reference itself)."""
+    g = load_golden("g9_vary_regularisation.npz")
+    r = orc.vary_regularisation(g["movie"], g["speed_alpha_values"], g["remodelling_alpha_values"], delta_x=0.5, delta_t=1.0)
+    for k in ("speed_means", "speed_variances", "remodelling_means", "remodelling_variances", "functional"):
+        np.testing.assert_allclose(r[k], g[k], rtol=1e-8, atol=1e-14, err_msg=k)
+    assert r["converged"].all() and r["speed_means"].shape == (2, 3)
