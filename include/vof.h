@@ -93,6 +93,12 @@ int vof_solve_stack_dev(vof_ctx* ctx, const double* movie, int n_frames, const v
                         double* v_x, double* v_y, double* remodelling, double* speed,
                         vof_pair_stats* stats);
 
+/* Replaces blur_movie (OF.py:282-306): per-frame Gaussian blur, scipy.ndimage.gaussian_filter semantics
+ * (mode='nearest'); weights = the 2*radius+1 normalised taps in host memory (radius = int(4*sigma + 0.5) for the
+ * reference's skimage call).  The context fixes the frame size; any number of frames. */
+int vof_blur_stack_dev(vof_ctx* ctx, const double* in_dev, double* out_dev, int n_frames, const double* weights, int radius);
+int vof_blur_stack_host(vof_ctx* ctx, const double* in_host, double* out_host, int n_frames, const double* weights, int radius);
+
 /* Smoother implementation: 1 (default) = fused streaming 4-colour sweep (one launch per sweep),
  * 0 = one launch per colour (the simple reference kernels, kept for A/B tests). */
 int vof_set_fused_sweeps(vof_ctx* ctx, int on);

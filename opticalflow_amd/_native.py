@@ -54,6 +54,8 @@ SIGNATURES = {
     "vof_solve_stack_host": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), _vp, _vp, _vp, _vp, _vp]),
     "vof_solve_stack_dev": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), _vp, _vp, _vp, _vp, _vp]),
     "vof_bench_sweeps_dev": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), C.c_int]),
+    "vof_blur_stack_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "vof_blur_stack_host": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "vof_profile_enable": (C.c_int, [_vp, C.c_int]),
     "vof_profile_reset": (C.c_int, [_vp]),
     "vof_profile_filter": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -195,6 +197,16 @@ class Solver:
                                           _ptr(remodelling), _ptr(speed), _ptr(st))
         self._check(rc, "vof_solve_stack_dev")
         return st
+
+    def blur_host(self, movie: np.ndarray, weights: np.ndarray):
+        """Gaussian blur of every frame on the device (host arrays in and out)."""
+        movie = np.ascontiguousarray(movie, dtype=np.float64)
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        assert movie.shape[1:] == (self.n_i, self.n_j) and weights.size % 2 == 1
+        out = np.empty_like(movie)
+        self._check(self.lib.vof_blur_stack_host(self.h, _ptr(movie), _ptr(out), movie.shape[0], _ptr(weights),
+                                                 weights.size // 2), "vof_blur_stack_host")
+        return out
 
     def bench_sweeps(self, movie, n_pairs, params, n_sweeps):
         self._check(self.lib.vof_bench_sweeps_dev(self.h, _ptr(movie), n_pairs, C.byref(params), n_sweeps),

@@ -68,6 +68,7 @@ struct vof_ctx {
     // staging for the host-pointer API (allocated lazily)
     double* st_movie = nullptr;
     double* st_out[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *blur_tmp = nullptr, *blur_w = nullptr, *blur_io = nullptr;   // Gaussian blur scratch (lazy)
     std::vector<void*> allocs;
     size_t bytes = 0;
     std::string err;
@@ -815,6 +816,48 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
             if (dst[i])
                 HIPCHK(hipMemcpyAsync(dst[i] + (size_t)k0 * fs, c->st_out[i], (size_t)np * fs * sizeof(double),
                                       hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// Per-frame Gaussian blur (replaces blur_movie, OF.py:282-306).  weights: the 2 * radius + 1 normalised taps
+// (host memory), exactly as scipy.ndimage builds them; in / out are device arrays of n_frames frames.
+int vof_blur_stack_dev(vof_ctx* c, const double* in, double* out, int n_frames, const double* weights, int radius) {
+    if (!c) return -1;
+    if (!in || !out || !weights) { c->err = "NULL pointer"; return -1; }
+    if (n_frames < 1 || radius < 0 || radius > 4096) { c->err = "bad n_frames / radius"; return -1; }
+    HIPCHK(hipSetDevice(c->device));
+    size_t fs = frame_stride(c);
+    const int chunk = std::min(n_frames, 16);
+    if (!c->blur_tmp) {
+        if (int rc = dev_alloc(c, &c->blur_tmp, (size_t)16 * fs)) return rc;
+        if (int rc = dev_alloc(c, &c->blur_w, (size_t)2 * 4096 + 1)) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(c->blur_w, weights, (size_t)(2 * radius + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        int nf = std::min(chunk, n_frames - f0);
+        dim3 g = grid2d(c->Ni, c->Nj, nf);
+        Prof p(c, VOF_K_RHS, 0);
+        k_blur1d<0><<<g, blk2d, 0, c->stream>>>(in + (size_t)f0 * fs, c->blur_tmp, c->Ni, c->Nj, c->blur_w, radius);
+        k_blur1d<1><<<g, blk2d, 0, c->stream>>>(c->blur_tmp, out + (size_t)f0 * fs, c->Ni, c->Nj, c->blur_w, radius);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vof_blur_stack_host(vof_ctx* c, const double* in, double* out, int n_frames, const double* weights, int radius) {
+    if (!c) return -1;
+    if (!in || !out || !weights) { c->err = "NULL pointer"; return -1; }
+    HIPCHK(hipSetDevice(c->device));
+    size_t fs = frame_stride(c);
+    if (!c->blur_io) { if (int rc = dev_alloc(c, &c->blur_io, (size_t)2 * 16 * fs)) return rc; }
+    for (int f0 = 0; f0 < n_frames; f0 += 16) {
+        int nf = std::min(16, n_frames - f0);
+        HIPCHK(hipMemcpyAsync(c->blur_io, in + (size_t)f0 * fs, (size_t)nf * fs * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (int rc = vof_blur_stack_dev(c, c->blur_io, c->blur_io + (size_t)16 * fs, nf, weights, radius)) return rc;
+        HIPCHK(hipMemcpyAsync(out + (size_t)f0 * fs, c->blur_io + (size_t)16 * fs, (size_t)nf * fs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     return 0;

@@ -1675,4 +1675,33 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
     }
 }
 
+// ==========================================================================================
+// Gaussian blur of the frames (OF.py:282-306: skimage.filters.gaussian == scipy.ndimage.gaussian_filter with
+// mode='nearest', truncate=4): two 1-D correlations, axis 0 then axis 1, with edge clamping.  The summation order
+// is the one of scipy's symmetric-kernel branch (NI_Correlate1D): centre tap first, then the mirrored pairs
+// from the outside in, so results agree with the host filter to the last bit or two.
+// ==========================================================================================
+template <int AXIS>
+__global__ __launch_bounds__(NT) void k_blur1d(const double* __restrict__ in, double* __restrict__ out, int Ni, int Nj,
+                                               const double* __restrict__ w, int radius) {
+    int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y, f = blockIdx.z;
+    if (i >= Ni || j >= Nj) return;
+    const double* src = in + (size_t)f * Ni * Nj;
+    double acc = src[(size_t)i * Nj + j] * w[radius];
+    for (int k = -radius; k < 0; ++k) {
+        double a, b;
+        if (AXIS == 0) {
+            int ia = min(max(i + k, 0), Ni - 1), ib = min(max(i - k, 0), Ni - 1);
+            a = src[(size_t)ia * Nj + j];
+            b = src[(size_t)ib * Nj + j];
+        } else {
+            int ja = min(max(j + k, 0), Nj - 1), jb = min(max(j - k, 0), Nj - 1);
+            a = src[(size_t)i * Nj + ja];
+            b = src[(size_t)i * Nj + jb];
+        }
+        acc += (a + b) * w[k + radius];
+    }
+    out[(size_t)f * Ni * Nj + (size_t)i * Nj + j] = acc;
+}
+
 }  // namespace vof

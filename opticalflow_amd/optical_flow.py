@@ -31,18 +31,32 @@ def make_fake_data_frame(x_position, y_position, sigma=1.0, width=20.0, include_
     return frame, delta_x
 
 
-def blur_movie(movie, smoothing_sigma):
-    """Per-frame Gaussian blur (OF.py:282-306).  The reference calls
-    ``skimage.filters.gaussian(frame, sigma, preserve_range=True)``, which is
-    ``scipy.ndimage.gaussian_filter(frame, sigma, mode='nearest', truncate=4.0)``; it is a host
-    pre-processing step of the caller, outside the solver hot path."""
-    import scipy.ndimage
+def gaussian_taps(sigma, truncate=4.0):
+    """The normalised 1-D taps scipy.ndimage.gaussian_filter uses for ``sigma`` (skimage passes truncate=4.0):
+    ``radius = int(truncate * sigma + 0.5)``, ``w = exp(-0.5 x^2 / sigma^2) / sum``."""
+    sigma = float(sigma)
+    radius = int(truncate * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum()
+
+
+def blur_movie(movie, smoothing_sigma, device=0, _solver=None):
+    """Per-frame Gaussian blur on the GPU, same arguments and result as OF.py:282-306.  The reference calls
+    ``skimage.filters.gaussian(frame, sigma, preserve_range=True)``, i.e. ``scipy.ndimage.gaussian_filter(frame,
+    sigma, mode='nearest', truncate=4.0)``: two 1-D correlations (axis 0, then axis 1) with clamped edges; the
+    HIP kernel keeps scipy's summation order, so the result agrees with the host filter to rounding."""
     movie = np.asarray(movie)
-    blurred = np.zeros_like(movie, dtype="double")
-    for index in range(movie.shape[0]):
-        blurred[index] = scipy.ndimage.gaussian_filter(movie[index].astype(np.float64), smoothing_sigma,
-                                                       mode="nearest", truncate=4.0)
-    return blurred
+    if movie.ndim != 3:
+        raise ValueError("movie must be a 3-D array (frames, x, y)")
+    taps = gaussian_taps(smoothing_sigma)
+    frames = np.ascontiguousarray(movie, dtype=np.float64)
+    if _solver is not None:
+        return _solver.blur_host(frames, taps)
+    with _native.Solver(max(4, movie.shape[1]), max(4, movie.shape[2]), 1, device=device) as solver:
+        if (solver.n_i, solver.n_j) != movie.shape[1:]:
+            raise ValueError("frames must be at least 4x4")
+        return solver.blur_host(frames, taps)
 
 
 def format_elapsed_time(time_difference):
@@ -119,7 +133,7 @@ def variational_optical_flow(movie,
     if movie.ndim != 3:
         raise ValueError("movie must be a 3-D array (frames, x, y)")
     if smoothing_sigma is not None:                                     # OF.py:770-773
-        movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma)
+        movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma, device=device, _solver=_solver)
     else:
         movie_to_analyse = movie
     T, N_i, N_j = movie.shape

@@ -95,8 +95,14 @@ def test_host_helpers_match_reference_semantics():
     fr, dx = of.make_fake_data_frame(1.3, 2.9, sigma=1.7, width=6.0, dimension=37)
     np.testing.assert_allclose(fr, g["frame"], rtol=4e-15)
     assert dx == float(g["delta_x"])
-    g4 = load_golden("g4_blur_64.npz")
-    np.testing.assert_allclose(of.blur_movie(g4["movie"], 2.0), g4["blurred"], rtol=0, atol=1e-15)
+    # the Gaussian taps handed to the device blur are scipy's
+    import scipy.ndimage
+    imp = np.zeros(41); imp[20] = 1.0
+    for sigma in (0.7, 2.0, 2.48):
+        taps = of.gaussian_taps(sigma)
+        r = taps.size // 2
+        np.testing.assert_allclose(taps, scipy.ndimage.gaussian_filter1d(imp, sigma, mode="constant")[20 - r:21 + r],
+                                   rtol=0, atol=1e-17)
     assert of.format_elapsed_time(125.25) == (2, 5, 250)
     a = np.arange(25.0).reshape(5, 5)
     of.apply_constant_boundary_condition(a)
