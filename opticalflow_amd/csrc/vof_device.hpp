@@ -1684,6 +1684,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
 template <int AXIS>
 __global__ __launch_bounds__(NT) void k_blur1d(const double* __restrict__ in, double* __restrict__ out, int Ni, int Nj,
                                                const double* __restrict__ w, int radius) {
+#pragma clang fp contract(off)   // no FMA: the host filter rounds the product and the sum separately
     int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y, f = blockIdx.z;
     if (i >= Ni || j >= Nj) return;
     const double* src = in + (size_t)f * Ni * Nj;
