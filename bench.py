@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--nu-post-coarse", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--gather-chunks", type=int, default=0, help="chunks of the stack whose all-gather overlaps the next solve")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (test)")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel HIP-event table (stderr)")
     args = ap.parse_args()
@@ -132,13 +133,20 @@ def main():
     gm = torch.empty_like(vx)
     sp = torch.empty_like(vx)
     gathered = None
+    n_chunks = 1
     if use_dist and not args.no_allgather:
+        # re-assembled stack, natural order: gathered[f][r * P + k] = field f of pair k of rank r
         gathered = [torch.empty((world * P, n, n), dtype=torch.float64, device=dev) for _ in range(3)]
+        # the stack is solved in a few chunks so that the all-gather of chunk i (RCCL stream) overlaps the solve of
+        # chunk i+1 (solver stream)
+        n_chunks = args.gather_chunks if args.gather_chunks > 0 else next((d for d in (3, 4, 5, 2) if P % d == 0), 1)
+        if P % n_chunks:
+            n_chunks = 1
     torch.cuda.synchronize()
 
     per_pair = _native.query_workspace(n, n, 1)
     free, total = _native.device_memory(local_rank)
-    B = args.pairs_in_flight or largest_batch(P, per_pair, 0.7 * free)
+    B = args.pairs_in_flight or largest_batch(P // n_chunks, per_pair, 0.7 * free)
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
                                     coarse_precision={"float64": 0, "float32": 1}[args.coarse_precision],
                                     vcycle_precision={"float64": 0, "float32": 1}[args.vcycle_precision],
@@ -148,11 +156,20 @@ def main():
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
     def step():
-        st = solver.solve_dev(movie, T, params, vx, vy, gm, sp, stats=True)   # syncs the solver's stream
-        if gathered is not None:
+        if gathered is None:
+            return solver.solve_dev(movie, T, params, vx, vy, gm, sp, stats=True)   # syncs the solver's stream
+        cl = P // n_chunks
+        works, stats_all = [], []
+        for i in range(n_chunks):
+            a, b_ = i * cl, (i + 1) * cl
+            stats_all.append(solver.solve_dev(movie[a:b_ + 1], cl + 1, params, vx[a:b_], vy[a:b_], gm[a:b_], sp[a:b_],
+                                              stats=True))          # returns after the solver's stream has drained
             for dst, src in zip(gathered, (vx, vy, gm)):
-                dist.all_gather_into_tensor(dst, src)
-        return st
+                outs = [dst[r * P + a: r * P + b_] for r in range(world)]
+                works.append(dist.all_gather(outs, src[a:b_], async_op=True))
+        for w in works:
+            w.wait()
+        return np.concatenate(stats_all)
 
     def barrier():
         torch.cuda.synchronize()
@@ -219,7 +236,7 @@ def main():
                                f"remodelling_alpha=1e4, rtol={args.rtol:g}, all {P} pairs solved to the stopping rule",
                    "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
                    "sweeps": [args.nu_pre, args.nu_post, args.nu_pre_coarse, args.nu_post_coarse],
-                   "allgather": gathered is not None,
+                   "allgather": gathered is not None, "gather_chunks": n_chunks,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),
                    "converged": bool(stats["converged"].all())},
