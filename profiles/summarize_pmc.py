@@ -59,7 +59,9 @@ def main():
         for sym, lst in by_sym.items():
             for pat, (nm, first_level) in names.items():
                 if pat in sym:
-                    for rank, (grid, n, rd, wr) in enumerate(sorted(lst, key=lambda t: -t[0])):
+                    # only the largest grid of a class is labelled (forward / reverse sweeps of the deeper levels have
+                    # different grid sizes, so a rank is not a level there)
+                    for rank, (grid, n, rd, wr) in enumerate(sorted(lst, key=lambda t: -t[0])[:1]):
                         k = f"{nm}_L{first_level + rank}_{size}x{size}x{frames}"
                         if k in out:       # several template instantiations of one class: keep the busiest
                             if out[k]["launches"] >= n:
