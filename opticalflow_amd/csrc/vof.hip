@@ -79,6 +79,7 @@ struct vof_ctx {
     bool hierarchy_float = false;
     bool fused = true;   // fused streaming 4-colour sweeps (false: one launch per colour)
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
+    bool fuse_prolong = true;   // level 0: coarse-grid correction interpolated inside the first post-sweep
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     // profiler
@@ -327,7 +328,7 @@ void coarse_solve_t(vof_ctx* c, const VT* r, VT* e, int np, const int* active) {
 // One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
 template <typename VT>
 void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
-                   const int* active) {
+                   const int* active, const VT* ecoarse = nullptr) {
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
     int rows = lv.ni + po;
@@ -338,26 +339,30 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
     const int nx = (lv.nj + (geoB ? 0 : po) + out - 1) / out, ny = (rows + TI - 1) / TI;
     dim3 g((unsigned)nx * ny * np, 1, 1);
     const double vs = sizeof(VT);
+    int nci = 0, ncj = 0;
+    double ebytes = 0.0;
+    if (ecoarse) { nci = c->L[l + 1].ni; ncj = c->L[l + 1].nj; ebytes = 3.0 * vs * c->L[l + 1].npts; }
     if (l == 0 && lv.C == nullptr) {
-        Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // I + b(3) + x(3) in, x(3) out
+        Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * vs) * lv.npts + ebytes);   // I + b(3) + x(3) in, x(3) out (+ coarse e)
         SweepFine pol;
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
         pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
-        size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double);
-        if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
-        else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+        size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double) +
+                     (ecoarse ? (size_t)(3 * 3 * (W / 2 + 2)) * sizeof(VT) : 0);
+        if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+        else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
     } else {
         const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
         Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
         if (c->hierarchy_float && l > 0) {
             SweepStored<float> pol; pol.C = (const float*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
-            if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
-            else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+            else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
         } else {
             SweepStored<double> pol; pol.C = (const double*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
-            if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
-            else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+            if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+            else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
         }
     }
 }
@@ -365,8 +370,16 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
 // nu sweeps (from a zero guess if from_zero, else from x); the result is guaranteed to end in `x`.
 template <typename VT>
 void smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
-                    const int* active) {
+                    const int* active, const VT* ecoarse = nullptr) {
+    // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
+    // into the first sweep (coarse rows streamed through LDS); otherwise the prolongation kernel runs first.
     const size_t bytes = (size_t)np * 3 * c->L[l].npts * sizeof(VT);
+    const bool fold = ecoarse && nu > 0 && c->fused && c->fuse_prolong && l == 0 && c->L[0].C == nullptr &&
+                      !c->geo_b_fine && !from_zero;
+    if (ecoarse && !fold) {
+        prolong_add_level_t<VT>(c, l, x, ecoarse, np, active);
+        ecoarse = nullptr;
+    }
     if (nu <= 0) {
         if (from_zero) hipMemsetAsync(x, 0, bytes, c->stream);
         return;
@@ -382,7 +395,7 @@ void smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool
     const VT* src = from_zero ? nullptr : x;
     VT* dst = (from_zero && (nu % 2 == 1)) ? x : tmp;
     for (int s = 0; s < nu; ++s) {
-        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active);
+        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr);
         src = dst;
         dst = (dst == x) ? tmp : x;
     }
@@ -406,8 +419,7 @@ void vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) 
         restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
     }
     vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
-    prolong_add_level_t<VT>(c, l, x, (const VT*)nx.x, np, active);
-    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active);
+    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active, (const VT*)nx.x);
 }
 
 void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
@@ -710,6 +722,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     }
     if (const char* e = getenv("VOF_STREAM_APPLY")) c->stream_apply = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_RESTRICT")) c->fuse_restrict = e[0] != '0';
+    if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
     c->L.push_back(l0);

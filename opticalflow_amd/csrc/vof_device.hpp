@@ -1133,11 +1133,17 @@ __device__ __forceinline__ SweepRows sweep_rows(const SweepGeom& g, int rr, int 
 template <class Pol, class G, typename VT>
 __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
                                                const VT* __restrict__ x_in, VT* __restrict__ x_out,
-                                               const VT* __restrict__ b, const int* __restrict__ active) {
+                                               const VT* __restrict__ b, const int* __restrict__ active,
+                                               const VT* __restrict__ ecoarse, int nci, int ncj) {
+    // ecoarse != nullptr (GeoA only): the sweep starts from x_in + P ecoarse.  The coarse rows are streamed through
+    // a 3-row LDS ring (one new coarse row per step, prefetched a step ahead) and interpolated while the fine rows
+    // are loaded, so the separate prolongation pass over x (read + write of x) disappears.
     constexpr int W = G::W, IW = G::IW, OUT = G::OUT, THREADS = G::THREADS;
     extern __shared__ double sw_lds[];
     VT* xs = reinterpret_cast<VT*>(sw_lds);                                                     // [SW_RING][3][W]
     double* im = reinterpret_cast<double*>(reinterpret_cast<char*>(sw_lds) + SW_RING * 3 * W * sizeof(VT));  // [SW_RING][IW]
+    constexpr int CRW = W / 2 + 2;                                                              // coarse ring width
+    VT* cr = reinterpret_cast<VT*>(im + (Pol::kHasImage ? SW_RING * IW : 0));                   // [3][3][CRW] (if ecoarse)
     const unsigned nblocks = (unsigned)nx * ny * nz;
     unsigned lb = blockIdx.x;
     if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // bijective when nblocks % 8 == 0
@@ -1156,6 +1162,8 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     const VT* xin = x_in ? x_in + off : nullptr;
     VT* xout = x_out + off;
     const VT* bp = b + off;
+    const size_t ncpts = (size_t)nci * ncj;
+    const VT* ec = (ecoarse && !G::HALO_WAVE) ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
     const double* img = nullptr;
     if (Pol::kHasImage) img = pol.frames + (size_t)pair * pol.frame_stride;
     const CLay L(ni, nj);
@@ -1212,6 +1220,27 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     const int fc0 = g.qs + ccol, fc1 = g.qs + 128 + ccol;     // full-image columns of image-ring columns ccol, 128 + ccol
     const bool iv0 = fc0 >= 0 && fc0 <= nj + 1, iv1 = ccol < 2 && fc1 >= 0 && fc1 <= nj + 1;
     const int ilds0 = sw_ci<G>(ccol), ilds1 = sw_ci<G>(ccol < 2 ? 128 + ccol : 0);
+    // coarse-correction ring: thread <-> (field, coarse column) of the row being prefetched; fine column q of
+    // this thread interpolates from coarse columns (q >> 1) and (q >> 1) + 1
+    const int cqs = g.qs >> 1;                                  // coarse column of ring column 0 (floor)
+    const int crf = tid / CRW, crc = tid % CRW;
+    const bool cr_on = ec && tid < 3 * CRW;
+    const int crq = cqs + crc;
+    const bool cr_cv = cr_on && crq >= 0 && crq < ncj;
+    const int ilcq = (int)(cqg >> 1) - cqs;                     // ring column of (q >> 1)
+    const bool ipj = ccv && (cq & 1) && ((cq >> 1) + 1 < ncj);
+    auto cr_slot = [](int k) { return ((k % 3) + 3) % 3; };
+    if (ec) {   // prologue: the two coarse rows the first load-in step needs
+        const int k0 = (g.p0 - 2) >> 1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int k = k0 + d;
+            VT v = (VT)0;
+            if (cr_cv && k >= 0 && k < nci) v = ec[(size_t)crf * ncpts + (size_t)k * ncj + crq];
+            if (cr_on) cr[(cr_slot(k) * 3 + crf) * CRW + crc] = v;
+        }
+        __syncthreads();
+    }
     int m_lds[3], m_rs[3];
     size_t m_g[3];
     bool m_ld[3], m_st[3];
@@ -1266,6 +1295,8 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
         VT lx[3];
         double li[KIMG > 2 ? KIMG : 2];
         const bool do_load = (e + 2 <= TI + 1);
+        VT crv = (VT)0;                                   // element of the coarse row prefetched in this step
+        const int knew = ((g.p0 + e + 4) >> 1) + 1;
         if (ROWMAP) {
             const int slotR = crow ? slotB : slotA;
             // (1) write-out of the row that became final: relative row e - 10 + crow
@@ -1284,7 +1315,26 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
             if (do_load && xin && pL >= 0 && pL < ni && ccv) {
                 const VT* irow = xin + (size_t)pL * nj + cqg;
                 lx[0] = irow[0]; lx[1] = irow[npts]; lx[2] = irow[2 * npts];
+                if (ec) {   // + (P e)(pL, q) from the coarse ring
+                    const int cp = pL >> 1;
+                    const bool ipi = (pL & 1) && (cp + 1 < nci);
+                    const double wi0 = ipi ? 0.5 : 1.0, wj0 = ipj ? 0.5 : 1.0;
+                    const VT* c0 = cr + cr_slot(cp) * 3 * CRW + ilcq;
+                    const VT* c1 = cr + cr_slot(cp + 1) * 3 * CRW + ilcq;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        double v = wi0 * wj0 * (double)c0[f * CRW];
+                        if (ipj) v += wi0 * 0.5 * (double)c0[f * CRW + 1];
+                        if (ipi) {
+                            v += 0.5 * wj0 * (double)c1[f * CRW];
+                            if (ipj) v += 0.25 * (double)c1[f * CRW + 1];
+                        }
+                        lx[f] = (VT)((double)lx[f] + v);
+                    }
+                }
             }
+            // coarse row needed by the NEXT step: ((p0 + e + 4) >> 1) + 1
+            if (ec && cr_cv && knew >= 0 && knew < nci) crv = ec[(size_t)crf * ncpts + (size_t)knew * ncj + crq];
             if (Pol::kHasImage) {
                 const int fr = pL + 1;
                 if (do_load && fr >= 0 && fr <= ni + 1) {
@@ -1363,6 +1413,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
                     im[slotR * IW + ilds0] = li[0];
                     if (ccol < 2) im[slotR * IW + ilds1] = li[1];
                 }
+                if (cr_on) cr[(cr_slot(knew) * 3 + crf) * CRW + crc] = crv;
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
