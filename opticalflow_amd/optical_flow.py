@@ -75,7 +75,7 @@ def apply_constant_boundary_condition(image):
     image[:, -1] = image[:, -3]
 
 
-def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=256):
+def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=96):
     """Largest batch of frame pairs whose workspace fits in ``memory_fraction`` of the free HBM."""
     free, _total = _native.device_memory(device)
     budget = free * memory_fraction
