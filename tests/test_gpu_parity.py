@@ -247,3 +247,25 @@ def test_vary_regularisation_against_reference_fixture(of, tmp_path):
     assert r["converged"].all() and r["converged"].dtype == bool
     saved = np.load(fn, allow_pickle=True).item()          # our own file (the reference's scripts read it this way)
     np.testing.assert_array_equal(saved["speed_means"], r["speed_means"])
+
+
+def test_full_size_properties_1024(of):
+    """BASELINE full frame size (1024x1024; the direct oracle is impractical there): size-independent properties -
+    stopping rule, independent CPU residual of one pair, mirror structure, known synthetic flow, determinism."""
+    movie = orc.make_texture_stack(1024, 3, seed=1)
+    res = of.variational_optical_flow(movie, remodelling_alpha=1e4, return_stats=True)
+    st = res["stats"]
+    assert st["converged"].all() and st["relative_residual"].max() <= 1.5e-6 and st["iterations"].max() <= 12
+    xi = np.stack([res["v_x"][1], res["v_y"][1], res["remodelling"][1]])[:, 1:-1, 1:-1]
+    b = orc.rhs_interior(movie[1], movie[2])
+    r = b - orc.apply_operator_interior(movie[1], xi, 1.0, 1e4)
+    assert np.linalg.norm(r) / np.linalg.norm(b) <= 1.5e-6
+    assert np.linalg.norm(r) / np.linalg.norm(b) == pytest.approx(st["relative_residual"][1], rel=1e-6)
+    for k in ("v_x", "v_y", "remodelling", "speed"):
+        f = res[k]
+        np.testing.assert_array_equal(f[:, 0, :], f[:, 2, :])
+        np.testing.assert_array_equal(f[:, :, -1], f[:, :, -3])
+    assert np.mean(res["v_x"]) == pytest.approx(0.3, abs=0.02) and np.mean(res["v_y"]) == pytest.approx(0.6, abs=0.02)
+    assert abs(np.mean(res["remodelling"])) < 5e-3
+    again = of.variational_optical_flow(movie, remodelling_alpha=1e4)
+    np.testing.assert_array_equal(again["v_x"], res["v_x"])          # bit-reproducible
