@@ -22,7 +22,7 @@ def build_native(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-shared", "-fPIC",
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-shared", "-fPIC", "-pthread",
            "-o", LIB] + SOURCES
     if verbose:
         print("[opticalflow_amd] " + " ".join(cmd), file=sys.stderr)
