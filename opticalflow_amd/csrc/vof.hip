@@ -370,8 +370,10 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
 
 // nu sweeps (from a zero guess if from_zero, else from x); the result is guaranteed to end in `x`.
 template <typename VT>
-void smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
-                    const int* active, const VT* ecoarse = nullptr) {
+VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
+                   const int* active, const VT* ecoarse = nullptr, bool allow_swap = false) {
+    // Returns the buffer that holds the result: `x`, or `tmp` when allow_swap is set and the last out-of-place sweep
+    // ended there (saves a device-to-device copy on the coarse levels).
     // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
     // into the first sweep (coarse rows streamed through LDS); otherwise the prolongation kernel runs first.
     const size_t bytes = (size_t)np * 3 * c->L[l].npts * sizeof(VT);
@@ -383,14 +385,14 @@ void smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool
     }
     if (nu <= 0) {
         if (from_zero) hipMemsetAsync(x, 0, bytes, c->stream);
-        return;
+        return x;
     }
     if (!c->fused) {   // reference path: one launch per colour, in place (double vectors only)
         if (from_zero) hipMemsetAsync(x, 0, bytes, c->stream);
         for (int s = 0; s < nu; ++s)
             for (int k = 0; k < 4; ++k)
                 gs_colour(c, l, (double*)x, (const double*)b, reverse ? 3 - k : k, np, active);
-        return;
+        return x;
     }
     // out-of-place fused sweeps: choose the first destination so that the last sweep writes into x
     const VT* src = from_zero ? nullptr : x;
@@ -400,14 +402,19 @@ void smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool
         src = dst;
         dst = (dst == x) ? tmp : x;
     }
-    if (src != x) hipMemcpyAsync(x, src, bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (src != x) {
+        if (allow_swap) return tmp;
+        hipMemcpyAsync(x, src, bytes, hipMemcpyDeviceToDevice, c->stream);
+    }
+    return x;
 }
 
 // One V-cycle: x (zero initial guess) ~= A^-1 b.
 template <typename VT>
-void vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) {
+// Returns the buffer holding the result: `x`, or (levels >= 1 only) the level's ping-pong partner.
+VT* vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) {
     int last = (int)c->L.size() - 1;
-    if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return; }
+    if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return x; }
     Level& lv = c->L[l];
     Level& nx = c->L[l + 1];
     const int nu1 = (l > 0 && c->prm.nu_pre_coarse > 0) ? c->prm.nu_pre_coarse : c->prm.nu_pre;
@@ -419,8 +426,8 @@ void vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) 
         apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
         restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
     }
-    vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
-    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active, (const VT*)nx.x);
+    const VT* ec = vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
+    return smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active, ec, /*allow_swap=*/l > 0);
 }
 
 void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
