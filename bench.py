@@ -87,10 +87,11 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="float32", choices=["float64", "float32"])
     ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32"])
-    ap.add_argument("--nu-pre", type=int, default=1)
+    ap.add_argument("--nu-pre", type=int, default=2)
     ap.add_argument("--nu-post", type=int, default=2)
     ap.add_argument("--nu-pre-coarse", type=int, default=1)
     ap.add_argument("--nu-post-coarse", type=int, default=1)
+    ap.add_argument("--w-cycle-level", type=int, default=None, help="-1: V-cycle; l: level l visits level l+1 twice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational mixed-precision variant run")
     ap.add_argument("--no-allgather", action="store_true")
@@ -153,6 +154,8 @@ def main():
                                     vcycle_precision={"float64": 0, "float32": 1}[args.vcycle_precision],
                                     nu_pre=args.nu_pre, nu_post=args.nu_post, nu_pre_coarse=args.nu_pre_coarse,
                                     nu_post_coarse=args.nu_post_coarse)
+    if args.w_cycle_level is not None:
+        params.w_cycle_level = args.w_cycle_level
     solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
@@ -237,6 +240,7 @@ def main():
                                f"remodelling_alpha=1e4, rtol={args.rtol:g}, all {P} pairs solved to the stopping rule",
                    "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
                    "sweeps": [args.nu_pre, args.nu_post, args.nu_pre_coarse, args.nu_post_coarse],
+                   "w_cycle_level": int(params.w_cycle_level),
                    "allgather": gathered is not None, "gather_chunks": n_chunks,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 100 /* 0.1.0 */
+#define VOF_VERSION 101 /* 0.1.1 */
 
 typedef struct vof_ctx vof_ctx;
 
@@ -38,13 +38,15 @@ typedef struct vof_params {
     double initial_remodelling;/* OF.py:723,802 */
     double rtol;               /* OF.py:1120: 1e-6, ||b - A x||_2 <= rtol ||b||_2 (unpreconditioned, OF.py:1126) */
     int32_t max_iterations;    /* OF.py:1120: 1000 BiCGStab iterations */
-    int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction on level 0 (default 1) */
+    int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction on level 0 (default 2) */
     int32_t nu_post;           /* ... and after (default 2) */
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
     int32_t coarse_precision;  /* 1 (default): float32 storage of the Galerkin stencils; 0: float64 */
     int32_t vcycle_precision;  /* 0 (default): float64 V-cycle vectors; 1: float32 storage (FP64 arithmetic, FP64 Krylov) */
     int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
     int32_t nu_post_coarse;
+    int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 twice per cycle (a one-level W-cycle); -1: V-cycle */
+    int32_t reserved;
 } vof_params;
 
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */

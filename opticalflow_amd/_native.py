@@ -23,7 +23,8 @@ class VofParams(C.Structure):
                 ("delta_t", C.c_double), ("initial_v_x", C.c_double), ("initial_v_y", C.c_double),
                 ("initial_remodelling", C.c_double), ("rtol", C.c_double), ("max_iterations", C.c_int32),
                 ("nu_pre", C.c_int32), ("nu_post", C.c_int32), ("reference_quirks", C.c_int32),
-                ("coarse_precision", C.c_int32), ("vcycle_precision", C.c_int32), ("nu_pre_coarse", C.c_int32), ("nu_post_coarse", C.c_int32)]
+                ("coarse_precision", C.c_int32), ("vcycle_precision", C.c_int32), ("nu_pre_coarse", C.c_int32), ("nu_post_coarse", C.c_int32),
+                ("w_cycle_level", C.c_int32), ("reserved", C.c_int32)]
 
 
 class VofPairStats(C.Structure):

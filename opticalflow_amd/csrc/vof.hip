@@ -409,29 +409,38 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
     return x;
 }
 
-// One V-cycle: x (zero initial guess) ~= A^-1 b.
+// One multigrid cycle on level l for A_l x = b, starting from a zero guess (from_zero) or from the contents of x.
+// (x, tmp) are the level's ping-pong buffers.  Returns the buffer holding the result: `x`, or - on the levels >= 1,
+// where the caller only reads it - `tmp`.  With prm.w_cycle_level == l the next coarser level is visited twice
+// (the second visit continues from the first one's result): a W-cycle restricted to one level.
 template <typename VT>
-// Returns the buffer holding the result: `x`, or (levels >= 1 only) the level's ping-pong partner.
-VT* vcycle_t(vof_ctx* c, int l, VT* x, const VT* b, int np, const int* active) {
+VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* active, bool from_zero = true) {
     int last = (int)c->L.size() - 1;
     if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return x; }
     Level& lv = c->L[l];
     Level& nx = c->L[l + 1];
     const int nu1 = (l > 0 && c->prm.nu_pre_coarse > 0) ? c->prm.nu_pre_coarse : c->prm.nu_pre;
     const int nu2 = (l > 0 && c->prm.nu_post_coarse > 0) ? c->prm.nu_post_coarse : c->prm.nu_post;
-    smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu1, true, false, np, active);
+    // pre-smoothing (result forced into x: the residual / post-smoothing below read x)
+    smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active);
     if (l == 0 && lv.C == nullptr && c->stream_apply && c->fuse_restrict) {
         resrestrict_fine_t<VT>(c, x, b, (VT*)nx.b, np, active);
     } else {
         apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
         restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
     }
-    const VT* ec = vcycle_t<VT>(c, l + 1, (VT*)nx.x, (const VT*)nx.b, np, active);
-    return smooth_level_t<VT>(c, l, x, (VT*)lv.x2, b, nu2, false, true, np, active, ec, /*allow_swap=*/l > 0);
+    VT* cx = (VT*)nx.x;
+    VT* ct = (VT*)nx.x2;
+    VT* ec = vcycle_t<VT>(c, l + 1, cx, ct, (const VT*)nx.b, np, active, true);
+    if (c->prm.w_cycle_level == l && l + 1 < last) {
+        VT* other = (ec == cx) ? ct : cx;
+        ec = vcycle_t<VT>(c, l + 1, ec, other, (const VT*)nx.b, np, active, false);
+    }
+    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/l > 0);
 }
 
 void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
-    VDISPATCH(c, vcycle_t<VT>(c, 0, (VT*)x, (const VT*)b, np, active));
+    VDISPATCH(c, vcycle_t<VT>(c, 0, (VT*)x, (VT*)c->L[0].x2, (const VT*)b, np, active));
 }
 
 // Build the Galerkin hierarchy and the coarsest-level dense inverse for the current batch.
@@ -622,6 +631,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (!(p->delta_x != 0.0) || !(p->delta_t != 0.0)) { c->err = "delta_x and delta_t must be non-zero"; return -1; }
     if (p->nu_pre < 0 || p->nu_post < 0 || p->nu_pre + p->nu_post == 0) { c->err = "nu_pre + nu_post must be > 0"; return -1; }
     if (p->nu_pre_coarse < 0 || p->nu_post_coarse < 0) { c->err = "nu_*_coarse must be >= 0"; return -1; }
+    if (p->w_cycle_level < -1 || p->w_cycle_level > 15) { c->err = "w_cycle_level must be -1 or a level index"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
     if (p->vcycle_precision != 0 && p->vcycle_precision != 1) { c->err = "vcycle_precision must be 0 or 1"; return -1; }
@@ -647,10 +657,11 @@ void vof_default_params(vof_params* p) {
     p->delta_t = 1.0;
     p->rtol = 1e-6;                // OF.py:1120
     p->max_iterations = 1000;      // OF.py:1120
-    p->nu_pre = 1;                 // V(1,2) on level 0 ...
+    p->nu_pre = 2;                 // (2,2) sweeps on level 0 ...
     p->nu_post = 2;
-    p->nu_pre_coarse = 1;          // ... V(1,1) on the stored-stencil levels (measured best time to solution)
+    p->nu_pre_coarse = 1;          // ... (1,1) on the stored-stencil levels (measured best time to solution)
     p->nu_post_coarse = 1;
+    p->w_cycle_level = 1;          // level 1 visits level 2 twice per cycle (one-level W-cycle: -20 % iterations)
     p->reference_quirks = 1;
     p->coarse_precision = 1;       // float32 storage of the Galerkin stencils (preconditioner only)
     p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)

@@ -102,6 +102,7 @@ def variational_optical_flow(movie,
                              coarse_precision="float32",
                              vcycle_precision="float64",
                              multigrid_sweeps=None,
+                             w_cycle_level=None,
                              verbose=False,
                              return_stats=False,
                              _solver=None):
@@ -126,6 +127,7 @@ def variational_optical_flow(movie,
         ``vcycle_precision`` (storage precision inside the multigrid preconditioner only; the Krylov
         iteration, the stopping rule and the result are float64 either way), ``multigrid_sweeps``
         (block-GS sweeps per V-cycle: ``(pre, post)`` on level 0 and optionally ``(pre, post)`` on the coarse levels),
+        ``w_cycle_level`` (-1: V-cycle; ``l``: level ``l`` visits level ``l+1`` twice per cycle),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals).
     """
@@ -153,6 +155,8 @@ def variational_optical_flow(movie,
         params.nu_pre, params.nu_post = ms[0], ms[1]
         if len(ms) == 4:
             params.nu_pre_coarse, params.nu_post_coarse = ms[2], ms[3]
+    if w_cycle_level is not None:        # -1: plain V-cycle; l: level l visits level l+1 twice per cycle
+        params.w_cycle_level = int(w_cycle_level)
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()

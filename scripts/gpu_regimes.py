@@ -17,17 +17,17 @@ def tex(n, T, seed, scale=1.0):
 
 cases = [("N  [0,1] a=1 b=1e4", 1.0, 1.0, 1e4), ("8bit a=1e5 b=1e3", 255.0, 1e5, 1e3), ("[0,1] a=10 b=1", 1.0, 10.0, 1.0),
          ("[0,1] a=1 b=1", 1.0, 1.0, 1.0), ("[0,1] a=0.5 b=1e3", 1.0, 0.5, 1e3), ("T  8bit a=1e4 b=1e2", 255.0, 1e4, 1e2)]
-sweeps = [(2, 2, 2, 2), (1, 2, 1, 1), (1, 1, 1, 1), (2, 2, 1, 1), (1, 2, 0, 1)]
+sweeps = [((2, 2, 2, 2), -1), ((2, 2, 1, 1), -1), ((2, 2, 1, 1), 1), ((1, 2, 1, 1), 1)]
 for n in (256, 512):
     for name, scale, al, be in cases:
         mv = tex(n, 4, 5, scale)
         row = []
-        for ms in sweeps:
+        for ms, wl in sweeps:
             t = time.time()
             r = of.variational_optical_flow(mv, speed_alpha=al, remodelling_alpha=be, multigrid_sweeps=ms, return_stats=True,
-                                            max_iterations=400)
+                                            max_iterations=400, w_cycle_level=wl)
             st = r["stats"]
-            row.append(f"{ms}: its {st['iterations'].max():3d} c{int(st['converged'].all())} {time.time()-t:5.2f}s")
+            row.append(f"{ms}W{wl}: its {st['iterations'].max():3d} c{int(st['converged'].all())} {time.time()-t:5.2f}s")
         print(n, name, " | ".join(row), flush=True)
 # Gaussian (the reference's enabled test regime)
 from opticalflow_amd.optical_flow import make_fake_data_frame
@@ -35,7 +35,8 @@ for n in (128, 512):
     fr = [make_fake_data_frame(2.5 + 0.1 * t, 2.5 + 0.2 * t, sigma=3, width=5, dimension=n)[0] + 0.05 * t for t in range(3)]
     mv = np.stack(fr)
     row = []
-    for ms in sweeps:
-        r = of.variational_optical_flow(mv, speed_alpha=1.0, remodelling_alpha=1e4, multigrid_sweeps=ms, return_stats=True)
-        row.append(f"{ms}: its {r['stats']['iterations'].max():3d} c{int(r['stats']['converged'].all())}")
+    for ms, wl in sweeps:
+        r = of.variational_optical_flow(mv, speed_alpha=1.0, remodelling_alpha=1e4, multigrid_sweeps=ms, return_stats=True,
+                                        w_cycle_level=wl)
+        row.append(f"{ms}W{wl}: its {r['stats']['iterations'].max():3d} c{int(r['stats']['converged'].all())}")
     print(n, "G gaussian a=1 b=1e4", " | ".join(row), flush=True)

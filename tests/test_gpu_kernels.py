@@ -116,7 +116,7 @@ def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, be
 def test_vcycle_matches_prototype(native, kind, shape, npairs, alpha, beta, seed):
     mv = make_case(kind, shape, npairs, seed)
     p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, nu_pre=2, nu_post=2,
-                              nu_pre_coarse=2, nu_post_coarse=2)
+                              nu_pre_coarse=2, nu_post_coarse=2, w_cycle_level=-1)
     with native.Solver(shape[0], shape[1], npairs) as s:
         s.debug_setup(mv, p)
         r = s.debug_rhs()
@@ -214,7 +214,7 @@ def test_float32_vcycle_vectors_building_blocks(native, kind, shape, npairs, alp
     """vcycle_precision=1: V-cycle vectors stored as float32, arithmetic FP64 -> float32-rounding agreement."""
     mv = make_case(kind, shape, npairs, seed)
     p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, vcycle_precision=1, coarse_precision=1,
-                              nu_pre=2, nu_post=2, nu_pre_coarse=2, nu_post_coarse=2)
+                              nu_pre=2, nu_post=2, nu_pre_coarse=2, nu_post_coarse=2, w_cycle_level=-1)
     rng = np.random.default_rng(seed)
     with native.Solver(shape[0], shape[1], npairs) as s:
         s.debug_setup(mv, p)
