@@ -42,7 +42,8 @@ typedef struct vof_params {
     int32_t nu_post;           /* ... and after (default 2) */
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
     int32_t coarse_precision;  /* 1 (default): float32 storage of the Galerkin stencils; 0: float64 */
-    int32_t vcycle_precision;  /* 0 (default): float64 V-cycle vectors; 1: float32 storage (FP64 arithmetic, FP64 Krylov) */
+    int32_t vcycle_precision;  /* V-cycle vectors: 0 (default) float64; 1 float32 storage; 2 auto = float32 for the first 8
+                                  iterations, float64 afterwards (arithmetic, Krylov vectors and stopping rule always FP64) */
     int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
     int32_t nu_post_coarse;
     int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 twice per cycle (a one-level W-cycle); -1: V-cycle */

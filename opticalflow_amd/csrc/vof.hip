@@ -24,6 +24,7 @@ namespace {
 
 constexpr int COARSEST_MAX = 9;      // coarsen until max(n_i, n_j) <= 9  (dense inverse of <= 243 unknowns)
 constexpr int MAX_PROF_RECS = 32768;
+constexpr int AUTO_F64_AFTER = 8;   // vcycle_precision == 2: switch the V-cycle vectors to float64 after this many iterations
 
 struct Level {
     int ni = 0, nj = 0;
@@ -571,6 +572,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         int nact = 0;
         for (int k = 0; k < np; ++k) nact += c->h_active[k] != 0;
         if (nact == 0) break;
+        // vcycle_precision 2 ("auto"): float32 V-cycle vectors for the first iterations, float64 for stragglers
+        // (in the slowly converging regimes float32 storage costs iterations)
+        if (P.vcycle_precision == 2 && it == AUTO_F64_AFTER) c->vfloat = false;
         c->cur_units = nact;
         const int* act = c->active;
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
@@ -634,10 +638,10 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->w_cycle_level < -1 || p->w_cycle_level > 15) { c->err = "w_cycle_level must be -1 or a level index"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
-    if (p->vcycle_precision != 0 && p->vcycle_precision != 1) { c->err = "vcycle_precision must be 0 or 1"; return -1; }
+    if (p->vcycle_precision < 0 || p->vcycle_precision > 2) { c->err = "vcycle_precision must be 0, 1 or 2"; return -1; }
     c->prm = *p;
     // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
-    c->vfloat = p->vcycle_precision == 1 && c->fused && c->L.size() > 1;
+    c->vfloat = p->vcycle_precision >= 1 && c->fused && c->L.size() > 1;
     return 0;
 }
 

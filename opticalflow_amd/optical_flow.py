@@ -124,8 +124,9 @@ def variational_optical_flow(movie,
       * keyword-only extras: ``rtol`` (default 1e-6 = OF.py:1120), ``max_iterations`` (1000),
         ``reference_quirks`` (True keeps OF.py:698-699 'dy'=='dx' and the OF.py:1205
         ``speed_functional`` assignment), ``device``, ``max_pairs_in_flight``, ``coarse_precision`` /
-        ``vcycle_precision`` (storage precision inside the multigrid preconditioner only; the Krylov
-        iteration, the stopping rule and the result are float64 either way), ``multigrid_sweeps``
+        ``vcycle_precision`` (storage precision inside the multigrid preconditioner only: "float64", "float32" or
+        "auto" = float32 for the first 8 iterations, float64 for stragglers; all arithmetic, the Krylov iteration, the
+        stopping rule and the result are float64 either way), ``multigrid_sweeps``
         (block-GS sweeps per V-cycle: ``(pre, post)`` on level 0 and optionally ``(pre, post)`` on the coarse levels),
         ``w_cycle_level`` (-1: V-cycle; ``l``: level ``l`` visits level ``l+1`` twice per cycle),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
@@ -149,7 +150,7 @@ def variational_optical_flow(movie,
         initial_remodelling=float(initial_remodelling), rtol=float(rtol), max_iterations=int(max_iterations),
         reference_quirks=int(bool(reference_quirks)),
         coarse_precision={"float64": 0, "float32": 1}[coarse_precision],
-        vcycle_precision={"float64": 0, "float32": 1}[vcycle_precision])
+        vcycle_precision={"float64": 0, "float32": 1, "auto": 2}[vcycle_precision])
     if multigrid_sweeps is not None:     # (pre, post) on level 0 [, (pre, post) on the coarse levels]
         ms = tuple(int(v) for v in multigrid_sweeps)
         params.nu_pre, params.nu_post = ms[0], ms[1]
