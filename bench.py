@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--nu-pre-coarse", type=int, default=1)
     ap.add_argument("--nu-post-coarse", type=int, default=1)
     ap.add_argument("--w-cycle-level", type=int, default=None, help="-1: V-cycle; l: level l visits level l+1 twice")
+    ap.add_argument("--w-cycle-visits", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational mixed-precision variant run")
     ap.add_argument("--no-allgather", action="store_true")
@@ -156,6 +157,8 @@ def main():
                                     nu_post_coarse=args.nu_post_coarse)
     if args.w_cycle_level is not None:
         params.w_cycle_level = args.w_cycle_level
+    if args.w_cycle_visits is not None:
+        params.w_cycle_visits = args.w_cycle_visits
     solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
@@ -240,7 +243,7 @@ def main():
                                f"remodelling_alpha=1e4, rtol={args.rtol:g}, all {P} pairs solved to the stopping rule",
                    "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
                    "sweeps": [args.nu_pre, args.nu_post, args.nu_pre_coarse, args.nu_post_coarse],
-                   "w_cycle_level": int(params.w_cycle_level),
+                   "w_cycle_level": int(params.w_cycle_level), "w_cycle_visits": int(params.w_cycle_visits),
                    "allgather": gathered is not None, "gather_chunks": n_chunks,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),
@@ -266,7 +269,7 @@ def main():
                     "relres_max": float(stv["relative_residual"].max()), "converged": bool(stv["converged"].all())}
         common = dict(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol, nu_pre=args.nu_pre, nu_post=args.nu_post,
                       nu_pre_coarse=args.nu_pre_coarse, nu_post_coarse=args.nu_post_coarse,
-                      w_cycle_level=int(params.w_cycle_level))
+                      w_cycle_level=int(params.w_cycle_level), w_cycle_visits=int(params.w_cycle_visits))
         out["variants"] = {
             "all_float64_storage": timed(_native.default_params(vcycle_precision=0, coarse_precision=0, **common)),
             "float32_stencils_auto_vectors": timed(_native.default_params(vcycle_precision=2, coarse_precision=1, **common)),

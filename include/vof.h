@@ -46,8 +46,8 @@ typedef struct vof_params {
                                   iterations, float64 afterwards (arithmetic, Krylov vectors and stopping rule always FP64) */
     int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
     int32_t nu_post_coarse;
-    int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 twice per cycle (a one-level W-cycle); -1: V-cycle */
-    int32_t reserved;
+    int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 w_cycle_visits times per cycle (a one-level W-cycle); -1: V-cycle */
+    int32_t w_cycle_visits;    /* visits of level w_cycle_level + 1 per cycle (default 3); 0 = 2 */
 } vof_params;
 
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */

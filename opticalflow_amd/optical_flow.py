@@ -156,8 +156,11 @@ def variational_optical_flow(movie,
         params.nu_pre, params.nu_post = ms[0], ms[1]
         if len(ms) == 4:
             params.nu_pre_coarse, params.nu_post_coarse = ms[2], ms[3]
-    if w_cycle_level is not None:        # -1: plain V-cycle; l: level l visits level l+1 twice per cycle
-        params.w_cycle_level = int(w_cycle_level)
+    if w_cycle_level is not None:        # -1: plain V-cycle; l or (l, visits): level l visits level l+1 several times
+        if isinstance(w_cycle_level, (tuple, list)):
+            params.w_cycle_level, params.w_cycle_visits = int(w_cycle_level[0]), int(w_cycle_level[1])
+        else:
+            params.w_cycle_level = int(w_cycle_level)
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()

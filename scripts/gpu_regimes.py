@@ -17,7 +17,7 @@ def tex(n, T, seed, scale=1.0):
 
 cases = [("N  [0,1] a=1 b=1e4", 1.0, 1.0, 1e4), ("8bit a=1e5 b=1e3", 255.0, 1e5, 1e3), ("[0,1] a=10 b=1", 1.0, 10.0, 1.0),
          ("[0,1] a=1 b=1", 1.0, 1.0, 1.0), ("[0,1] a=0.5 b=1e3", 1.0, 0.5, 1e3), ("T  8bit a=1e4 b=1e2", 255.0, 1e4, 1e2)]
-sweeps = [((2, 2, 2, 2), -1), ((2, 2, 1, 1), -1), ((2, 2, 1, 1), 1), ((1, 2, 1, 1), 1)]
+sweeps = [((2, 2, 2, 2), -1), ((2, 2, 1, 1), (1, 2)), ((2, 2, 1, 1), (1, 3)), ((2, 2, 1, 1), (1, 4))]
 for n in (256, 512):
     for name, scale, al, be in cases:
         mv = tex(n, 4, 5, scale)

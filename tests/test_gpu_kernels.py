@@ -256,3 +256,35 @@ def test_float32_vcycle_vectors_building_blocks(native, kind, shape, npairs, alp
             assert relerr(e[k], H[k].vcycle(r[k], 2, 2)) < 1e-3
         with pytest.raises(native.VofError, match="float64"):
             s.debug_gs(0, x, b, 0)
+
+
+def test_w_cycle_matches_prototype(native):
+    """One-level W-cycle (level 1 visits level 2 three times, each visit continuing from the previous result) against
+    the numpy prototype of the same recursion."""
+    shape, npairs, alpha, beta = (130, 130), 1, 1.0, 1e4
+    mv = make_case("texture", shape, npairs, 3)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, nu_pre=2, nu_post=2,
+                              nu_pre_coarse=1, nu_post_coarse=1, w_cycle_level=1, w_cycle_visits=3)
+    H = mg.Hierarchy(mv[0], alpha, beta)
+
+    def cyc(b, level, x0=None):
+        C = H.levels[level]
+        if level == len(H.levels) - 1:
+            return (H.coarse_inv @ b.ravel()).reshape(b.shape)
+        nu = 2 if level == 0 else 1
+        x = np.zeros_like(b) if x0 is None else x0.copy()
+        mg.smooth(C, x, b, nu)
+        rc = mg.restrict(b - mg.apply_stencil(C, x))
+        ec = cyc(rc, level + 1)
+        if level == 1 and level + 1 < len(H.levels) - 1:
+            for _ in range(2):
+                ec = cyc(rc, level + 1, x0=ec)
+        x += mg.prolong(ec, *x.shape[-2:])
+        mg.smooth(C, x, b, nu, reverse=True)
+        return x
+
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        r = s.debug_rhs()
+        e = s.debug_vcycle(r)
+        assert relerr(e[0], cyc(r[0], 0)) < 1e-9
