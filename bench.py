@@ -125,6 +125,7 @@ def main():
 
     from opticalflow_amd import _native
     from opticalflow_amd.synthetic import texture_stack_torch
+    from opticalflow_amd.distributed import allgather_chunk
 
     n, T = args.size, args.frames
     P = T - 1
@@ -172,8 +173,7 @@ def main():
             stats_all.append(solver.solve_dev(movie[a:b_ + 1], cl + 1, params, vx[a:b_], vy[a:b_], gm[a:b_], sp[a:b_],
                                               stats=True))          # returns after the solver's stream has drained
             for dst, src in zip(gathered, (vx, vy, gm)):
-                outs = [dst[r * P + a: r * P + b_] for r in range(world)]
-                works.append(dist.all_gather(outs, src[a:b_], async_op=True))
+                works.append(allgather_chunk(dst, src, a, b_, P))
         for w in works:
             w.wait()
         return np.concatenate(stats_all)

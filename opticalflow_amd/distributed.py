@@ -86,3 +86,15 @@ def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=No
     result["converged"] = bool(flags[last_rank].item())
     result["L1_functional"], result["remodelling_functional"], result["speed_functional"] = (float(v) for v in s.cpu())
     return result
+
+
+def allgather_chunk(gathered, local, a, b, n_pairs_per_rank, group=None, async_op=True):
+    """Start the all-gather of pairs [a, b) of this rank's ``local`` (n_pairs_per_rank, N_i, N_j) tensor into the
+    re-assembled stack ``gathered`` ((world * n_pairs_per_rank, N_i, N_j), natural order: rank r's pair k at
+    ``r * n_pairs_per_rank + k``).  Returns the work handle (``.wait()``) when ``async_op``.  Used by bench.py to
+    overlap the exchange of one chunk with the solve of the next."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    P = n_pairs_per_rank
+    outs = [gathered[r * P + a: r * P + b] for r in range(world)]
+    return dist.all_gather(outs, local[a:b], group=group, async_op=async_op)

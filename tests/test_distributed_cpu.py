@@ -80,3 +80,42 @@ def test_two_rank_gloo_sharded_solve_matches_single_process(n_frames):
         assert L1 == pytest.approx(ref["L1_functional"], rel=1e-9)
         assert sf == pytest.approx(ref["speed_functional"], rel=1e-9)
         assert conv is True
+
+
+def _gather_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+        from opticalflow_amd.distributed import allgather_chunk
+        P, n = 6, 5
+        local = (torch.arange(P * n * n, dtype=torch.float64).reshape(P, n, n) + 1000.0 * rank)
+        gathered = torch.full((world * P, n, n), -1.0, dtype=torch.float64)
+        works = [allgather_chunk(gathered, local, a, a + 2, P) for a in (0, 2, 4)]     # 3 chunks, asynchronous
+        for w in works:
+            w.wait()
+        q.put((rank, gathered.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_allgather_reassembles_in_natural_order():
+    """bench.py's multi-GPU step: chunk-wise asynchronous all-gathers into the rank-major output stack."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P, n = 6, 5
+    expect = np.concatenate([np.arange(P * n * n, dtype=np.float64).reshape(P, n, n) + 1000.0 * r for r in range(world)])
+    for rank, g in got:
+        np.testing.assert_array_equal(g, expect)
