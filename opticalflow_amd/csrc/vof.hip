@@ -206,12 +206,22 @@ void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np
 
 // y = A_l x (mode 0) or y = b - A_l x (mode 1); XT/BT/YT storage types (level 0 matrix-free),
 // stored levels use one type for all three.
+// Band height of the row-streaming kernels: bands of <= 128 rows (balanced, even).  A block marches through its band
+// sequentially, so a launch lasts at least (band height / 2 + pipeline depth) steps; when only a few pairs are still
+// active (the tail iterations of a batch, or a small stack) the grid does not fill the 256 CUs and shorter bands
+// (more, shorter blocks) cut that latency floor.
+int pick_band_height(int rows, int nx, int units) {
+    const long blocks128 = (long)nx * ((rows + 127) / 128) * std::max(1, units);
+    const int cap = blocks128 < 768 ? 32 : (blocks128 < 1536 ? 64 : 128);   // 768 = 3 blocks per CU
+    const int nb = (rows + cap - 1) / cap;
+    return std::max(2, (((rows + nb - 1) / nb + 1) / 2) * 2);
+}
+
 // Geometry of the streaming level-0 operator kernel: 128-column strips, bands of <= 128 rows (even height).
 struct ApplyGrid { int TI, nblk; dim3 grid; };
 ApplyGrid apply_grid(const vof_ctx* c, int np) {
     const Level& lv = c->L[0];
-    int nb = (lv.ni + 127) / 128;
-    int TI = std::max(2, (((lv.ni + nb - 1) / nb + 1) / 2) * 2);
+    int TI = pick_band_height(lv.ni, (lv.nj + AP_OUT - 1) / AP_OUT, c->cur_units);
     ApplyGrid g;
     g.TI = TI;
     g.grid = dim3((lv.nj + AP_OUT - 1) / AP_OUT, (lv.ni + TI - 1) / TI, np);
@@ -305,8 +315,7 @@ void restrict_level_t(vof_ctx* c, int l, const VT* fine, VT* coarse, int np, con
 template <typename VT>
 void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, VT* bc, int np, const int* active) {
     Level &f = c->L[0], &k = c->L[1];
-    int nbands = (f.ni + 127) / 128;
-    int TI = std::max(2, (((f.ni + nbands - 1) / nbands + 1) / 2) * 2);
+    int TI = pick_band_height(f.ni, (k.nj + RR_CO - 1) / RR_CO, c->cur_units);
     dim3 g((k.nj + RR_CO - 1) / RR_CO, (k.ni + TI / 2 - 1) / (TI / 2), np);
     Prof p(c, VOF_K_APPLY0, 0, (8.0 + 6.0 * sizeof(VT)) * f.npts + 3.0 * sizeof(VT) * k.npts);
     k_stream_resrestrict0<VT, VT, VT><<<g, AP_THREADS, 0, c->stream>>>(
@@ -334,10 +343,9 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
     int rows = lv.ni + po;
-    int nb = (rows + 127) / 128;                       // bands of <= 128 rows, balanced, even height
-    int TI = std::max(2, (((rows + nb - 1) / nb + 1) / 2) * 2);
     const bool geoB = (l > 0) ? c->geo_b_stored : c->geo_b_fine;
     const int out = geoB ? GeoB::OUT : GeoA::OUT, W = geoB ? GeoB::W : GeoA::W, IW = geoB ? GeoB::IW : GeoA::IW;
+    const int TI = pick_band_height(rows, (lv.nj + (geoB ? 0 : po) + out - 1) / out, c->cur_units);
     const int nx = (lv.nj + (geoB ? 0 : po) + out - 1) / out, ny = (rows + TI - 1) / TI;
     dim3 g((unsigned)nx * ny * np, 1, 1);
     const double vs = sizeof(VT);
@@ -783,8 +791,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (int rc = dev_alloc(c, &c->invT, (size_t)B * c->nd * c->nd)) return rc;
     c->nblk = (int)std::min<size_t>(256, std::max<size_t>(1, (len0 + 4 * RBLK - 1) / (4 * RBLK)));
     {
-        int nb = (l0.ni + 127) / 128, TI = std::max(2, (((l0.ni + nb - 1) / nb + 1) / 2) * 2);
-        int nblk_apply = ((l0.nj + AP_OUT - 1) / AP_OUT) * ((l0.ni + TI - 1) / TI);
+        int nblk_apply = ((l0.nj + AP_OUT - 1) / AP_OUT) * ((l0.ni + 31) / 32 + 1);   // smallest band height: 32 rows
         if (int rc = dev_alloc(c, &c->partials, (size_t)B * 3 * std::max(c->nblk, nblk_apply))) return rc;
     }
     if (int rc = dev_alloc(c, &c->sc, (size_t)B)) return rc;
