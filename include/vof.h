@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 101 /* 0.1.1 */
+#define VOF_VERSION 102 /* 0.1.2 */
 
 typedef struct vof_ctx vof_ctx;
 
@@ -101,6 +101,36 @@ int vof_solve_stack_dev(vof_ctx* ctx, const double* movie, int n_frames, const v
  * reference's skimage call).  The context fixes the frame size; any number of frames. */
 int vof_blur_stack_dev(vof_ctx* ctx, const double* in_dev, double* out_dev, int n_frames, const double* weights, int radius);
 int vof_blur_stack_host(vof_ctx* ctx, const double* in_host, double* out_host, int n_frames, const double* weights, int radius);
+
+/* Summary of one (speed_alpha, remodelling_alpha) combination of vary_regularisation (OF.py:1978-1983). */
+typedef struct vof_variation_stats {
+    double speed_mean, speed_variance;             /* np.mean / np.var of result['speed'] (OF.py:1978-1979) */
+    double remodelling_mean, remodelling_variance; /* ... of result['remodelling'] (OF.py:1980-1981) */
+    double L1_functional, speed_functional, remodelling_functional; /* sums over the pairs; speed_functional is the true
+                                                      alpha * sum |grad u|^2 (the caller applies the OF.py:1205 quirk) */
+    double max_relative_residual;                  /* worst pair */
+    int32_t converged_last;                        /* flag of the last pair = result['converged'] (OF.py:1202, 1982) */
+    int32_t converged_all;                         /* 1 if every pair met the stopping rule */
+    int32_t max_iterations_used;                   /* worst pair */
+    int32_t reserved;
+} vof_variation_stats;
+
+/* Replaces vary_regularisation (OF.py:1918-1998): every (speed_alphas[i], remodelling_alphas[j]) combination is an
+ * independent solve of the same movie.  The movie is uploaded (and blurred, if blur_weights != NULL; taps as for
+ * vof_blur_stack_*) once, all solves and the mean / variance reductions run on the device, and only the summaries
+ * cross PCIe.  base: all other parameters.  out: n_speed_alphas * n_remodelling_alphas entries, row-major [i][j]. */
+int vof_vary_regularisation_host(vof_ctx* ctx, const double* movie, int n_frames, const vof_params* base,
+                                 const double* speed_alphas, int n_speed_alphas,
+                                 const double* remodelling_alphas, int n_remodelling_alphas,
+                                 const double* blur_weights, int blur_radius, vof_variation_stats* out);
+
+/* Mean and (population) variance of n device-resident doubles, deterministic two-pass reduction. */
+int vof_field_moments_dev(vof_ctx* ctx, const double* field_dev, size_t n, double* mean, double* variance);
+
+/* Replaces the sampling loop of subsample_velocities_for_visualisation (OF.py:1614-1632) for a device-resident
+ * field stack (n_fields, n_i, n_j): out[k][a][b] = field[k][a*box + offset][b*box + offset], a < n_i / box,
+ * b < n_j / box (the reference uses offset = round(box / 2)).  out_dev: (n_fields, n_i/box, n_j/box) doubles. */
+int vof_subsample_dev(vof_ctx* ctx, const double* field_dev, int n_fields, int box, int offset, double* out_dev);
 
 /* Smoother implementation: 1 (default) = fused streaming 4-colour sweep (one launch per sweep),
  * 0 = one launch per colour (the simple reference kernels, kept for A/B tests). */

@@ -38,6 +38,13 @@ STATS_DTYPE = np.dtype([("iterations", np.int32), ("converged", np.int32), ("rel
                         ("remodelling_functional", np.float64)])
 assert STATS_DTYPE.itemsize == C.sizeof(VofPairStats)
 
+VARIATION_DTYPE = np.dtype([("speed_mean", np.float64), ("speed_variance", np.float64), ("remodelling_mean", np.float64),
+                            ("remodelling_variance", np.float64), ("L1_functional", np.float64),
+                            ("speed_functional", np.float64), ("remodelling_functional", np.float64),
+                            ("max_relative_residual", np.float64), ("converged_last", np.int32),
+                            ("converged_all", np.int32), ("max_iterations_used", np.int32), ("reserved", np.int32)])
+assert VARIATION_DTYPE.itemsize == 80     # sizeof(vof_variation_stats)
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -57,6 +64,9 @@ SIGNATURES = {
     "vof_bench_sweeps_dev": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), C.c_int]),
     "vof_blur_stack_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "vof_blur_stack_host": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "vof_vary_regularisation_host": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "vof_field_moments_dev": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vof_subsample_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "vof_profile_enable": (C.c_int, [_vp, C.c_int]),
     "vof_profile_reset": (C.c_int, [_vp]),
     "vof_profile_filter": (C.c_int, [_vp, C.c_int, C.c_int]),
@@ -85,6 +95,26 @@ class VofError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  If
+    libvof.so pulled in the system runtime first and torch were imported later, the process would hold two runtimes and
+    the second one finds no GPU.  Load torch's copy first (without importing torch) so that libvof.so binds to it and the
+    process has ONE runtime whichever is used first.  No torch installed: the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path: str | None = None):
     """Load libvof.so and declare all prototypes.  Raises if the library is absent (build it with
     ``python -m opticalflow_amd.build`` or ``__graft_entry__.build()``)."""
@@ -95,6 +125,7 @@ def load_library(path: str | None = None):
     if not os.path.exists(p):
         raise VofError(f"native library {p} not found: build it with `python -m opticalflow_amd.build` "
                        "(hipcc, gfx950). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -208,6 +239,37 @@ class Solver:
         self._check(self.lib.vof_blur_stack_host(self.h, _ptr(movie), _ptr(out), movie.shape[0], _ptr(weights),
                                                  weights.size // 2), "vof_blur_stack_host")
         return out
+
+    def blur_dev(self, movie, out, n_frames, weights: np.ndarray):
+        """Gaussian blur of ``n_frames`` device-resident frames (``out`` may alias ``movie``)."""
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        self._check(self.lib.vof_blur_stack_dev(self.h, _ptr(movie), _ptr(out), int(n_frames), _ptr(weights),
+                                                weights.size // 2), "vof_blur_stack_dev")
+
+    def vary_regularisation_host(self, movie: np.ndarray, params: VofParams, speed_alphas, remodelling_alphas, weights=None):
+        """The whole (speed_alpha, remodelling_alpha) sweep of vary_regularisation on the device; returns a structured
+        array (VARIATION_DTYPE) of shape (len(speed_alphas), len(remodelling_alphas))."""
+        movie = np.ascontiguousarray(movie, dtype=np.float64)
+        assert movie.shape[1:] == (self.n_i, self.n_j)
+        sa = np.ascontiguousarray(speed_alphas, dtype=np.float64).ravel()
+        ra = np.ascontiguousarray(remodelling_alphas, dtype=np.float64).ravel()
+        out = np.zeros((sa.size, ra.size), dtype=VARIATION_DTYPE)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        rc = self.lib.vof_vary_regularisation_host(self.h, _ptr(movie), movie.shape[0], C.byref(params), _ptr(sa), sa.size,
+                                                   _ptr(ra), ra.size, _ptr(w), 0 if w is None else w.size // 2, _ptr(out))
+        self._check(rc, "vof_vary_regularisation_host")
+        return out
+
+    def field_moments_dev(self, field, n):
+        """(mean, population variance) of ``n`` device-resident doubles."""
+        m, v = C.c_double(), C.c_double()
+        self._check(self.lib.vof_field_moments_dev(self.h, _ptr(field), int(n), C.byref(m), C.byref(v)), "vof_field_moments_dev")
+        return m.value, v.value
+
+    def subsample_dev(self, field, n_fields, box, offset, out):
+        """out[k, a, b] = field[k, a*box + offset, b*box + offset] on device memory."""
+        self._check(self.lib.vof_subsample_dev(self.h, _ptr(field), int(n_fields), int(box), int(offset), _ptr(out)),
+                    "vof_subsample_dev")
 
     def bench_sweeps(self, movie, n_pairs, params, n_sweeps):
         self._check(self.lib.vof_bench_sweeps_dev(self.h, _ptr(movie), n_pairs, C.byref(params), n_sweeps),

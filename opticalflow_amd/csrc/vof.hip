@@ -935,6 +935,126 @@ int vof_blur_stack_host(vof_ctx* c, const double* in, double* out, int n_frames,
     return 0;
 }
 
+// sum (x - shift), sum (x - shift)^2 over n device doubles -> out2 (host); uses ctx->partials / func3 as scratch
+static int moments_pass(vof_ctx* c, const double* x, size_t n, double shift, double* out2) {
+    const int nb = c->nblk;
+    Prof p(c, VOF_K_REDUCE, 0, 8.0 * n);
+    k_moments<<<nb, RBLK, 0, c->stream>>>(x, n, shift, c->partials);
+    k_sum3<<<1, 64, 0, c->stream>>>(c->partials, nb, c->func3);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_func3, c->func3, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    out2[0] = c->h_func3[0];
+    out2[1] = c->h_func3[1];
+    return 0;
+}
+
+// (count, mean, M2 = sum (x - mean)^2) of one chunk, exact two-pass; chunks are merged with Chan's formula
+struct Moments {
+    double n = 0, mean = 0, m2 = 0;
+    void merge(double nb, double meanb, double m2b) {
+        if (nb == 0) return;
+        double nt = n + nb, d = meanb - mean;
+        m2 += m2b + d * d * n * nb / nt;
+        mean += d * nb / nt;
+        n = nt;
+    }
+};
+
+static int chunk_moments(vof_ctx* c, const double* x, size_t n, Moments* acc) {
+    double s[2];
+    if (int rc = moments_pass(c, x, n, 0.0, s)) return rc;
+    double mean = s[0] / (double)n;
+    if (int rc = moments_pass(c, x, n, mean, s)) return rc;
+    mean += s[0] / (double)n;                                      // first-order correction of the rounded mean
+    acc->merge((double)n, mean, s[1] - s[0] * s[0] / (double)n);
+    return 0;
+}
+
+int vof_field_moments_dev(vof_ctx* c, const double* field, size_t n, double* mean, double* variance) {
+    if (!c) return -1;
+    if (!field || n == 0) { c->err = "empty field"; return -1; }
+    HIPCHK(hipSetDevice(c->device));
+    Moments m;
+    if (int rc = chunk_moments(c, field, n, &m)) return rc;
+    if (mean) *mean = m.mean;
+    if (variance) *variance = m.m2 / m.n;
+    return 0;
+}
+
+int vof_subsample_dev(vof_ctx* c, const double* field, int n_fields, int box, int offset, double* out) {
+    if (!c) return -1;
+    if (!field || !out) { c->err = "NULL pointer"; return -1; }
+    if (n_fields < 1 || box < 1 || offset < 0 || offset >= box) { c->err = "bad n_fields / box / offset"; return -1; }
+    HIPCHK(hipSetDevice(c->device));
+    int nbx = c->Ni / box, nby = c->Nj / box;
+    if (nbx < 1 || nby < 1) return 0;
+    k_subsample<<<grid2d(nbx, nby, n_fields), blk2d, 0, c->stream>>>(field, c->Ni, c->Nj, box, offset, nbx, nby, out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, const vof_params* base,
+                                 const double* speed_alphas, int n_sa, const double* remodelling_alphas, int n_ra,
+                                 const double* blur_weights, int blur_radius, vof_variation_stats* out) {
+    if (!c) return -1;
+    if (!movie || !base || !out || !speed_alphas || !remodelling_alphas) { c->err = "NULL pointer"; return -1; }
+    if (n_frames < 2) { c->err = "need at least two frames"; return -1; }
+    if (n_sa < 0 || n_ra < 0) { c->err = "negative grid size"; return -1; }
+    if (int rc = check_params(c, base)) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t fs = frame_stride(c);
+    const int P = n_frames - 1;
+    if (!c->st_movie) {   // per-batch output staging shared with the host API
+        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
+        for (int i = 0; i < 4; ++i)
+            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
+    }
+    // the whole movie stays resident for the sweep (freed on return)
+    double* dmovie = nullptr;
+    HIPCHK(hipMalloc((void**)&dmovie, (size_t)n_frames * fs * sizeof(double)));
+    auto fail = [&](int rc) { (void)hipFree(dmovie); return rc; };
+    if (hipMemcpyAsync(dmovie, movie, (size_t)n_frames * fs * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        c->err = "H2D copy failed";
+        return fail(-2);
+    }
+    if (blur_weights)
+        if (int rc = vof_blur_stack_dev(c, dmovie, dmovie, n_frames, blur_weights, blur_radius)) return fail(rc);
+    std::vector<vof_pair_stats> st((size_t)P);
+    for (int i = 0; i < n_sa; ++i)
+        for (int j = 0; j < n_ra; ++j) {
+            vof_params q = *base;
+            q.speed_alpha = speed_alphas[i];
+            q.remodelling_alpha = remodelling_alphas[j];
+            if (int rc = check_params(c, &q)) return fail(rc);
+            Moments ms, mr;
+            for (int k0 = 0; k0 < P; k0 += c->B) {
+                int np = std::min(c->B, P - k0);
+                if (int rc = solve_batch(c, dmovie + (size_t)k0 * fs, np, c->st_out[0], c->st_out[1], c->st_out[2],
+                                         c->st_out[3], st.data() + k0)) return fail(rc);
+                if (int rc = chunk_moments(c, c->st_out[3], (size_t)np * fs, &ms)) return fail(rc);
+                if (int rc = chunk_moments(c, c->st_out[2], (size_t)np * fs, &mr)) return fail(rc);
+            }
+            vof_variation_stats& o = out[(size_t)i * n_ra + j];
+            memset(&o, 0, sizeof o);
+            o.speed_mean = ms.mean; o.speed_variance = ms.m2 / ms.n;
+            o.remodelling_mean = mr.mean; o.remodelling_variance = mr.m2 / mr.n;
+            o.converged_all = 1;
+            for (int k = 0; k < P; ++k) {
+                o.L1_functional += st[k].L1_functional;
+                o.speed_functional += st[k].speed_functional;
+                o.remodelling_functional += st[k].remodelling_functional;
+                o.max_relative_residual = std::max(o.max_relative_residual, st[k].relative_residual);
+                o.max_iterations_used = std::max(o.max_iterations_used, st[k].iterations);
+                o.converged_all &= st[k].converged;
+            }
+            o.converged_last = st[P - 1].converged;
+        }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return fail(0);
+}
+
 int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof_params* p, int n_sweeps) {
     if (!c) return -1;
     if (!movie) { c->err = "NULL movie"; return -1; }

@@ -926,6 +926,29 @@ __global__ void k_sum3(const double* __restrict__ partials, int nblk, double* __
     }
 }
 
+// Shifted power sums of a field, sum (x - shift) and sum (x - shift)^2, for the mean / variance summaries of
+// vary_regularisation (OF.py:1978-1981: np.mean / np.var of the speed and remodelling stacks).  Two passes (shift = 0,
+// then shift = mean) give the variance without cancellation; partials are combined in fixed order by k_sum3.
+__global__ __launch_bounds__(RBLK) void k_moments(const double* __restrict__ x, size_t n, double shift,
+                                                  double* __restrict__ partials) {
+    double s1 = 0, s2 = 0;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < n; i += (size_t)gridDim.x * RBLK) {
+        double d = x[i] - shift;
+        s1 += d;
+        s2 += d * d;
+    }
+    block_store_partials(s1, s2, 0.0, partials, 3, gridDim.x, 0, blockIdx.x);
+}
+
+// Strided sample of a field stack (subsample_velocities_for_visualisation, OF.py:1614-1632):
+// out[k][a][b] = field[k][a * box + offset][b * box + offset].
+__global__ void k_subsample(const double* __restrict__ field, int Ni, int Nj, int box, int offset, int nbx, int nby,
+                            double* __restrict__ out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
+    if (a >= nbx || b >= nby) return;
+    out[((size_t)k * nbx + a) * nby + b] = field[((size_t)k * Ni + (size_t)a * box + offset) * Nj + (size_t)b * box + offset];
+}
+
 
 // ==========================================================================================
 // Fused 4-colour block-GS sweep, streaming over rows (the north-star kernel).

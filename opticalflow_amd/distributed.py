@@ -98,3 +98,44 @@ def allgather_chunk(gathered, local, a, b, n_pairs_per_rank, group=None, async_o
     P = n_pairs_per_rank
     outs = [gathered[r * P + a: r * P + b] for r in range(world)]
     return dist.all_gather(outs, local[a:b], group=group, async_op=async_op)
+
+
+_VARIATION_KEYS = ("speed_means", "speed_variances", "remodelling_means", "remodelling_variances", "functional", "converged")
+
+
+def vary_regularisation_sharded(movie, speed_alpha_values, remodelling_alpha_values, sweep_fn=None, group=None,
+                                device=None, filename=None, **kwargs):
+    """``vary_regularisation`` (OF.py:1918-1998) across all ranks of ``group``: the flattened list of
+    ``(speed_alpha, remodelling_alpha)`` combinations is cut into contiguous ranges (``shard_pair_range``), each rank
+    runs the native sweep on its range, and one all-reduce of the six small summary tables re-assembles the result on
+    every rank (each entry is written by exactly one rank).  ``sweep_fn(movie, speed_alphas, remodelling_alphas,
+    **kwargs) -> dict`` defaults to the single-GPU ``optical_flow.vary_regularisation`` on this rank's device."""
+    import torch
+    import torch.distributed as dist
+    if sweep_fn is None:
+        from .optical_flow import vary_regularisation as sweep_fn
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        kwargs.setdefault("device", device.index)
+    if device is None:
+        device = torch.device("cpu")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_sa, n_ra = len(speed_alpha_values), len(remodelling_alpha_values)
+    start, stop = shard_pair_range(n_sa * n_ra, world, rank)
+    tables = np.zeros((len(_VARIATION_KEYS), n_sa, n_ra))
+    for i in range(n_sa):                     # this rank's part of row i: columns [j0, j1)
+        j0, j1 = max(start, i * n_ra) - i * n_ra, min(stop, (i + 1) * n_ra) - i * n_ra
+        if j1 <= j0:
+            continue
+        part = sweep_fn(movie, np.asarray(speed_alpha_values)[i:i + 1], np.asarray(remodelling_alpha_values)[j0:j1], **kwargs)
+        for t, key in enumerate(_VARIATION_KEYS):
+            tables[t, i, j0:j1] = np.asarray(part[key], dtype=np.float64)[0]
+    buf = torch.as_tensor(tables, device=device)
+    dist.all_reduce(buf, group=group)
+    tables = buf.cpu().numpy()
+    result = {"speed_alpha_values": speed_alpha_values, "remodelling_alpha_values": remodelling_alpha_values}
+    for t, key in enumerate(_VARIATION_KEYS):
+        result[key] = tables[t] > 0.5 if key == "converged" else tables[t]
+    if filename is not None and rank == 0:
+        np.save(filename, result)
+    return result

@@ -15,7 +15,9 @@ import numpy as np
 from . import _native
 
 __all__ = ["variational_optical_flow", "vary_regularisation", "make_fake_data_frame", "blur_movie",
-           "format_elapsed_time", "apply_constant_boundary_condition", "choose_pairs_in_flight"]
+           "format_elapsed_time", "apply_constant_boundary_condition", "choose_pairs_in_flight",
+           "subsample_velocities_for_visualisation", "costum_imshow", "make_velocity_overlay_movie",
+           "make_joint_overlay_movie"]
 
 
 def make_fake_data_frame(x_position, y_position, sigma=1.0, width=20.0, include_noise=False, dimension=1000):
@@ -83,6 +85,32 @@ def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap
     return int(max(1, min(n_pairs, cap, budget // max(per_pair, 1))))
 
 
+def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
+                   use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
+                   multigrid_sweeps, w_cycle_level):
+    """vof_params from the keyword arguments of ``variational_optical_flow``."""
+    if rtol is None:
+        rtol = 1e-11 if use_direct_solver else 1e-6
+    params = _native.default_params(
+        speed_alpha=float(speed_alpha), remodelling_alpha=float(remodelling_alpha), delta_x=float(delta_x),
+        delta_t=float(delta_t), initial_v_x=float(initial_v_x), initial_v_y=float(initial_v_y),
+        initial_remodelling=float(initial_remodelling), rtol=float(rtol), max_iterations=int(max_iterations),
+        reference_quirks=int(bool(reference_quirks)),
+        coarse_precision={"float64": 0, "float32": 1}[coarse_precision],
+        vcycle_precision={"float64": 0, "float32": 1, "auto": 2}[vcycle_precision])
+    if multigrid_sweeps is not None:     # (pre, post) on level 0 [, (pre, post) on the coarse levels]
+        ms = tuple(int(v) for v in multigrid_sweeps)
+        params.nu_pre, params.nu_post = ms[0], ms[1]
+        if len(ms) == 4:
+            params.nu_pre_coarse, params.nu_post_coarse = ms[2], ms[3]
+    if w_cycle_level is not None:        # -1: plain V-cycle; l or (l, visits): level l visits level l+1 several times
+        if isinstance(w_cycle_level, (tuple, list)):
+            params.w_cycle_level, params.w_cycle_visits = int(w_cycle_level[0]), int(w_cycle_level[1])
+        else:
+            params.w_cycle_level = int(w_cycle_level)
+    return params
+
+
 def variational_optical_flow(movie,
                              delta_x=1.0,
                              delta_t=1.0,
@@ -105,6 +133,7 @@ def variational_optical_flow(movie,
                              w_cycle_level=None,
                              verbose=False,
                              return_stats=False,
+                             output="numpy",
                              _solver=None):
     """Variational optical flow with remodelling on an image stack, on one MI355X.
 
@@ -130,8 +159,19 @@ def variational_optical_flow(movie,
         (block-GS sweeps per V-cycle: ``(pre, post)`` on level 0 and optionally ``(pre, post)`` on the coarse levels),
         ``w_cycle_level`` (-1: V-cycle; ``l``: level ``l`` visits level ``l+1`` twice per cycle),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
-        converged / functionals).
+        converged / functionals), ``output`` ("numpy": host arrays as in the reference; "torch": ``movie`` may be a
+        torch tensor already on the device and every array of the result stays on the device as a float64 torch
+        tensor - blur, solve and epilogue without PCIe traffic, see ``subsample_velocities_for_visualisation``).
     """
+    if output == "torch":
+        return _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_in_flight, verbose, return_stats,
+                                                reference_quirks, _solver_params(
+                                                    speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y,
+                                                    initial_remodelling, use_direct_solver, rtol, max_iterations,
+                                                    reference_quirks, coarse_precision, vcycle_precision, multigrid_sweeps,
+                                                    w_cycle_level), delta_x, delta_t)
+    if output != "numpy":
+        raise ValueError("output must be 'numpy' or 'torch'")
     movie = np.asarray(movie).astype(np.float64)                       # OF.py:769
     if movie.ndim != 3:
         raise ValueError("movie must be a 3-D array (frames, x, y)")
@@ -142,25 +182,9 @@ def variational_optical_flow(movie,
     T, N_i, N_j = movie.shape
     if T < 2:
         raise ValueError("movie needs at least two frames")
-    if rtol is None:
-        rtol = 1e-11 if use_direct_solver else 1e-6
-    params = _native.default_params(
-        speed_alpha=float(speed_alpha), remodelling_alpha=float(remodelling_alpha), delta_x=float(delta_x),
-        delta_t=float(delta_t), initial_v_x=float(initial_v_x), initial_v_y=float(initial_v_y),
-        initial_remodelling=float(initial_remodelling), rtol=float(rtol), max_iterations=int(max_iterations),
-        reference_quirks=int(bool(reference_quirks)),
-        coarse_precision={"float64": 0, "float32": 1}[coarse_precision],
-        vcycle_precision={"float64": 0, "float32": 1, "auto": 2}[vcycle_precision])
-    if multigrid_sweeps is not None:     # (pre, post) on level 0 [, (pre, post) on the coarse levels]
-        ms = tuple(int(v) for v in multigrid_sweeps)
-        params.nu_pre, params.nu_post = ms[0], ms[1]
-        if len(ms) == 4:
-            params.nu_pre_coarse, params.nu_post_coarse = ms[2], ms[3]
-    if w_cycle_level is not None:        # -1: plain V-cycle; l or (l, visits): level l visits level l+1 several times
-        if isinstance(w_cycle_level, (tuple, list)):
-            params.w_cycle_level, params.w_cycle_visits = int(w_cycle_level[0]), int(w_cycle_level[1])
-        else:
-            params.w_cycle_level = int(w_cycle_level)
+    params = _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
+                            use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
+                            multigrid_sweeps, w_cycle_level)
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()
@@ -198,55 +222,221 @@ def variational_optical_flow(movie,
     return result
 
 
+def _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_in_flight, verbose, return_stats,
+                                     reference_quirks, params, delta_x, delta_t):
+    """``output="torch"`` branch of ``variational_optical_flow``: torch only allocates the device arrays."""
+    import torch
+    dev = torch.device("cuda", int(device))
+    movie = torch.as_tensor(movie).to(device=dev, dtype=torch.float64).contiguous()      # OF.py:769
+    if movie.ndim != 3:
+        raise ValueError("movie must be a 3-D array (frames, x, y)")
+    T, N_i, N_j = movie.shape
+    if T < 2:
+        raise ValueError("movie needs at least two frames")
+    if max_pairs_in_flight is None:
+        max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, int(device))
+    out = [torch.empty((T - 1, N_i, N_j), dtype=torch.float64, device=dev) for _ in range(4)]
+    torch.cuda.synchronize(dev)          # the library launches on its own stream
+    with _native.Solver(N_i, N_j, max_pairs_in_flight, device=int(device)) as solver:
+        if smoothing_sigma is not None:                                                  # OF.py:770-773
+            taps = gaussian_taps(smoothing_sigma)
+            movie_to_analyse = torch.empty_like(movie)
+            solver.blur_dev(movie, movie_to_analyse, T, taps)
+        else:
+            movie_to_analyse = movie
+        stats = solver.solve_dev(movie_to_analyse, T, params, out[0], out[1], out[2], out[3])
+    if verbose:
+        print(f"iterations {stats['iterations'].tolist()}, converged {stats['converged'].astype(bool).tolist()}")
+    result = dict(v_x=out[0], v_y=out[1], speed=out[3], remodelling=out[2], original_data=movie, delta_x=delta_x,
+                  delta_t=delta_t, blurred_data=movie_to_analyse, converged=bool(stats["converged"][-1]),
+                  L1_functional=float(np.sum(stats["L1_functional"])),
+                  remodelling_functional=float(np.sum(stats["remodelling_functional"])))
+    result["speed_functional"] = (result["remodelling_functional"] if reference_quirks          # OF.py:1205
+                                  else float(np.sum(stats["speed_functional"])))
+    if return_stats:
+        result["stats"] = stats
+    return result
+
+
 def vary_regularisation(movie,
                         speed_alpha_values=np.arange(500, 2000, 500),
                         remodelling_alpha_values=np.arange(500, 2000, 500),
                         filename=None,
                         **kwargs):
     """Vary both regularisation parameters and keep the summary statistics for heat-maps; same arguments,
-    result dictionary and optional ``np.save`` as the reference (OF.py:1918-1998).  Every
-    ``(speed_alpha, remodelling_alpha)`` combination is an independent solve of the same movie; one device
-    workspace is created once and re-used for all of them, each solve batches all frame pairs.
+    result dictionary and optional ``np.save`` as the reference (OF.py:1918-1998).  ``kwargs`` are the keyword
+    arguments of ``variational_optical_flow`` (OF.py:1974-1977).
+
+    Every ``(speed_alpha, remodelling_alpha)`` combination is an independent solve of the same movie.  The whole sweep
+    is one native call (``vof_vary_regularisation_host``): the movie is uploaded and blurred once, each combination
+    batches all frame pairs, and ``np.mean`` / ``np.var`` of the speed and remodelling stacks (OF.py:1978-1981) are
+    two-pass reductions on the device, so only the summary scalars cross PCIe.
 
     Returns a dict with ``speed_alpha_values``, ``remodelling_alpha_values``, ``speed_means``,
     ``speed_variances``, ``remodelling_means``, ``remodelling_variances``, ``converged`` and ``functional``
     (``L1_functional + speed_functional + remodelling_functional``, OF.py:1983), each of shape
-    ``(len(speed_alpha_values), len(remodelling_alpha_values))``.
+    ``(len(speed_alpha_values), len(remodelling_alpha_values))``.  Extra keyword: ``return_stats=True`` adds
+    ``result['stats']`` (the native per-combination records: worst residual / iteration count, all-pairs flag).
     """
     movie = np.asarray(movie)
     if movie.ndim != 3:
         raise ValueError("movie must be a 3-D array (frames, x, y)")
-    shape = (len(speed_alpha_values), len(remodelling_alpha_values))
-    speed_means = np.zeros(shape)
-    speed_variances = np.zeros_like(speed_means)
-    remodelling_means = np.zeros_like(speed_means)
-    remodelling_variances = np.zeros_like(speed_means)
-    converged = np.zeros_like(speed_means, dtype=bool)
-    total_variations = np.zeros_like(speed_means)
     T, N_i, N_j = movie.shape
-    device = kwargs.get("device", 0)
-    pairs = kwargs.pop("max_pairs_in_flight", None) or choose_pairs_in_flight(N_i, N_j, T - 1, device)
-    with _native.Solver(N_i, N_j, pairs, device=device) as solver:
-        for i, speed_alpha in enumerate(speed_alpha_values):
-            for j, remodelling_alpha in enumerate(remodelling_alpha_values):
-                result = variational_optical_flow(movie, speed_alpha=speed_alpha, remodelling_alpha=remodelling_alpha,
-                                                  _solver=solver, **kwargs)
-                speed_means[i, j] = np.mean(result["speed"])
-                speed_variances[i, j] = np.var(result["speed"])
-                remodelling_means[i, j] = np.mean(result["remodelling"])
-                remodelling_variances[i, j] = np.var(result["remodelling"])
-                converged[i, j] = result["converged"]
-                total_variations[i, j] = (result["L1_functional"] + result["speed_functional"]
-                                          + result["remodelling_functional"])
+    if T < 2:
+        raise ValueError("movie needs at least two frames")
+    kw = dict(delta_x=1.0, delta_t=1.0, smoothing_sigma=None, initial_v_x=0.0, initial_v_y=0.0, initial_remodelling=0.0,
+              use_direct_solver=False, rtol=None, max_iterations=1000, reference_quirks=True, device=0,
+              max_pairs_in_flight=None, coarse_precision="float32", vcycle_precision="float64", multigrid_sweeps=None,
+              w_cycle_level=None, verbose=False, return_stats=False)
+    for k in kwargs:
+        if k not in kw:
+            raise TypeError(f"variational_optical_flow() got an unexpected keyword argument {k!r}")
+    kw.update(kwargs)
+    params = _solver_params(1.0, 1.0, kw["delta_x"], kw["delta_t"], kw["initial_v_x"], kw["initial_v_y"],
+                            kw["initial_remodelling"], kw["use_direct_solver"], kw["rtol"], kw["max_iterations"],
+                            kw["reference_quirks"], kw["coarse_precision"], kw["vcycle_precision"],
+                            kw["multigrid_sweeps"], kw["w_cycle_level"])
+    taps = None if kw["smoothing_sigma"] is None else gaussian_taps(kw["smoothing_sigma"])
+    pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, T - 1, kw["device"])
+    with _native.Solver(N_i, N_j, pairs, device=kw["device"]) as solver:
+        rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,
+                                              remodelling_alpha_values, taps)
+    if kw["verbose"]:
+        for i, a in enumerate(speed_alpha_values):
+            for j, b in enumerate(remodelling_alpha_values):
+                print(f"speed_alpha {a}, remodelling_alpha {b}: max iterations {rec['max_iterations_used'][i, j]}, "
+                      f"max relative residual {rec['max_relative_residual'][i, j]:.3e}, "
+                      f"all converged {bool(rec['converged_all'][i, j])}")
+    # OF.py:1205 stores the remodelling sum under 'speed_functional'; OF.py:1983 adds the three dict entries
+    speed_functional = rec["remodelling_functional"] if kw["reference_quirks"] else rec["speed_functional"]
     result_dict = {}
     result_dict["speed_alpha_values"] = speed_alpha_values
     result_dict["remodelling_alpha_values"] = remodelling_alpha_values
-    result_dict["speed_means"] = speed_means
-    result_dict["speed_variances"] = speed_variances
-    result_dict["remodelling_means"] = remodelling_means
-    result_dict["remodelling_variances"] = remodelling_variances
-    result_dict["converged"] = converged
-    result_dict["functional"] = total_variations
+    result_dict["speed_means"] = rec["speed_mean"].copy()
+    result_dict["speed_variances"] = rec["speed_variance"].copy()
+    result_dict["remodelling_means"] = rec["remodelling_mean"].copy()
+    result_dict["remodelling_variances"] = rec["remodelling_variance"].copy()
+    result_dict["converged"] = rec["converged_last"].astype(bool)       # OF.py:1982: flag of the last pair
+    result_dict["functional"] = rec["L1_functional"] + speed_functional + rec["remodelling_functional"]
+    if kw["return_stats"]:
+        result_dict["stats"] = rec
     if filename is not None:
         np.save(filename, result_dict)
     return result_dict
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Result consumers (SURVEY 8(f) rank 4): the steps the reference's scripts run right after the solve.
+# ---------------------------------------------------------------------------------------------------------
+def subsample_velocities_for_visualisation(flow_result, iteration=None, arrow_boxsize=5):
+    """Arrow positions and velocities for ``plt.quiver``, same arguments and return values as OF.py:1574-1646:
+    one sample per ``arrow_boxsize`` x ``arrow_boxsize`` box, taken at pixel ``box_index * arrow_boxsize +
+    round(arrow_boxsize / 2)`` (Python's ``round``, i.e. half-to-even, as in the reference); positions are in
+    ``delta_x`` units.  Returns ``(x_positions, y_positions, v_x, v_y)`` with the velocities of shape
+    ``(T-1, N_i // arrow_boxsize, N_j // arrow_boxsize)``.
+
+    A device-resident result (``output="torch"``) is sampled by a HIP gather kernel and only the
+    ``1 / arrow_boxsize^2`` samples cross PCIe.  ``iteration`` selects ``'v_x_steps'`` / ``'v_y_steps'`` entries
+    (OF.py:1621-1625), which only the reference's iterative legacy solvers produce."""
+    box = int(arrow_boxsize)
+    if box < 1:
+        raise ValueError("arrow_boxsize must be >= 1")
+    offset = round(arrow_boxsize / 2)
+    if iteration is not None:
+        fields = [flow_result["v_x_steps"][:, iteration], flow_result["v_y_steps"][:, iteration]]
+    else:
+        fields = [flow_result["v_x"], flow_result["v_y"]]
+    n_pairs = flow_result["original_data"].shape[0] - 1
+    n_x, n_y = fields[0].shape[1], fields[1].shape[2]
+    nbx, nby = n_x // box, n_y // box
+    if hasattr(fields[0], "data_ptr") and fields[0].is_cuda:
+        import torch
+        sub = []
+        with _native.Solver(n_x, n_y, 1, device=fields[0].device.index) as solver:
+            for f in fields:
+                out = torch.empty((n_pairs, nbx, nby), dtype=torch.float64, device=f.device)
+                torch.cuda.synchronize(f.device)
+                solver.subsample_dev(f[:n_pairs].contiguous(), n_pairs, box, offset, out)
+                sub.append(out.cpu().numpy())
+    else:
+        sub = [np.array(np.asarray(f)[:n_pairs, offset:offset + (nbx - 1) * box + 1:box,
+                                      offset:offset + (nby - 1) * box + 1:box], dtype=np.float64)
+               if nbx and nby else np.zeros((n_pairs, nbx, nby)) for f in fields]
+    delta_x = flow_result["delta_x"]
+    x_positions = (np.arange(nbx) * box + offset).astype(float) / n_x * (n_x * delta_x)
+    y_positions = (np.arange(nby) * box + offset).astype(float) / n_y * (n_y * delta_x)
+    return x_positions, y_positions, sub[0], sub[1]
+
+
+def costum_imshow(image, delta_x, cmap="gray_r", autoscale=False, v_min=0.0, v_max=255.0, unit=r"$\mathrm{\mu}$m"):
+    """Show an image without anti-aliasing, axes in physical units (same name, arguments and look as OF.py:1531-1572;
+    the figure / axes are created by the caller)."""
+    import matplotlib.pyplot as plt
+    limits = dict(vmin=None, vmax=None) if autoscale else dict(vmin=v_min, vmax=v_max)
+    extent = [0, image.shape[1] * delta_x, image.shape[0] * delta_x, 0]
+    plt.imshow(image, cmap=cmap, extent=extent, interpolation=None, **limits)
+    plt.xlabel("y-position [" + unit + "]")
+    plt.ylabel("x-position [" + unit + "]")
+
+
+def _quiver(x_positions, y_positions, v_x, v_y, arrow_color, arrow_scale, arrow_width):
+    # image rows run downwards: plot (y, x) with the x-velocity flipped (OF.py:1695)
+    import matplotlib.pyplot as plt
+    plt.quiver(y_positions, x_positions, v_y, -v_x, color=arrow_color, headwidth=5, scale=1.0 / arrow_scale,
+               width=arrow_width)
+
+
+def make_velocity_overlay_movie(flow_result, filename, arrow_boxsize=5, arrow_scale=1.0, cmap="gray_r", autoscale=False,
+                                arrow_color="magenta", arrow_width=None, v_min=0.0, v_max=255.0, dpi=600):
+    """Movie of the data with the flow arrows on top; arguments as OF.py:1649-1700 (``dpi`` is an extra)."""
+    import matplotlib.pyplot as plt
+    from matplotlib.animation import FuncAnimation
+    movie = flow_result["original_data"]
+    xs, ys, v_x, v_y = subsample_velocities_for_visualisation(flow_result, arrow_boxsize=arrow_boxsize)
+    fig = plt.figure(figsize=(2.5, 2.5))
+
+    def animate(i):
+        plt.cla()
+        costum_imshow(movie[i + 1], delta_x=flow_result["delta_x"], cmap=cmap, autoscale=autoscale, v_min=v_min, v_max=v_max)
+        _quiver(xs, ys, v_x[i], v_y[i], arrow_color, arrow_scale, arrow_width)
+        if i < 1:
+            plt.tight_layout()
+    FuncAnimation(fig, animate, frames=movie.shape[0] - 1).save(filename, dpi=dpi)
+    plt.close(fig)
+
+
+def make_joint_overlay_movie(flow_result, filename, arrow_boxsize=5, arrow_scale=1.0, arrow_width=None, cmap="gray_r",
+                             autoscale=False, arrow_color="magenta", v_min=0.0, v_max=255.0, dpi=600):
+    """Six-panel movie: data and blurred data with arrows, speed, net remodelling, v_x, v_y; arguments as
+    OF.py:1825-1916 (``dpi`` is an extra)."""
+    import matplotlib.pyplot as plt
+    import matplotlib.ticker
+    from matplotlib.animation import FuncAnimation
+    xs, ys, v_x, v_y = subsample_velocities_for_visualisation(flow_result, arrow_boxsize=arrow_boxsize)
+    dx = flow_result["delta_x"]
+    data_panels = [(231, "original_data", "Original data"), (232, "blurred_data", "Blurred")]
+    field_panels = [(233, "speed", "viridis", r"Motion speed [$\mathrm{\mu m}$/s]", False),
+                    (234, "remodelling", "plasma", "Net remodelling", False),
+                    (235, "v_x", "plasma", r"x velocity [$\mathrm{\mu m}$/s]", True),
+                    (236, "v_y", "plasma", r"y velocity [$\mathrm{\mu m}$/s]", False)]
+    ranges = {key: (np.min(flow_result[key]), np.max(flow_result[key])) for _, key, _, _, _ in field_panels}
+    fig = plt.figure(figsize=(6.5, 4.5), constrained_layout=True)
+
+    def animate(i):
+        plt.clf()
+        for pos, key, title in data_panels:
+            plt.subplot(pos)
+            costum_imshow(flow_result[key][i], delta_x=dx, cmap=cmap, autoscale=autoscale, v_min=v_min, v_max=v_max)
+            _quiver(xs, ys, v_x[i], v_y[i], arrow_color, arrow_scale, arrow_width)
+            plt.title(title)
+        for pos, key, field_cmap, title, keep_ylabel in field_panels:
+            plt.subplot(pos)
+            costum_imshow(flow_result[key][i], delta_x=dx, autoscale=True, cmap=field_cmap)
+            if not keep_ylabel:
+                plt.ylabel("")
+            colorbar = plt.colorbar(shrink=0.6)
+            plt.clim(*ranges[key])
+            colorbar.formatter = matplotlib.ticker.StrMethodFormatter("{x:.2f}")
+            plt.title(title)
+    FuncAnimation(fig, animate, frames=flow_result["original_data"].shape[0] - 1).save(filename, dpi=dpi)
+    plt.close(fig)

@@ -383,3 +383,23 @@ def vary_regularisation(movie, speed_alpha_values, remodelling_alpha_values, **k
     out["speed_alpha_values"] = speed_alpha_values
     out["remodelling_alpha_values"] = remodelling_alpha_values
     return out
+
+
+def subsample_velocities_for_visualisation(flow_result, arrow_boxsize=5):
+    """Oracle restatement of OF.py:1574-1646 (final-result branch): one sample per box at
+    ``box_index * arrow_boxsize + round(arrow_boxsize / 2)`` (Python round), positions in delta_x units."""
+    n_frames = flow_result["original_data"].shape[0]
+    n_x, n_y = flow_result["v_x"].shape[1], flow_result["v_y"].shape[2]
+    x_extent, y_extent = n_x * flow_result["delta_x"], n_y * flow_result["delta_x"]
+    nbx, nby = int(n_x / arrow_boxsize), int(n_y / arrow_boxsize)
+    half = round(arrow_boxsize / 2)
+    sub_x = np.zeros((n_frames - 1, nbx, nby))
+    sub_y = np.zeros((n_frames - 1, nbx, nby))
+    for k in range(n_frames - 1):
+        for a in range(nbx):
+            for b in range(nby):
+                sub_x[k, a, b] = flow_result["v_x"][k, a * arrow_boxsize + half, b * arrow_boxsize + half]
+                sub_y[k, a, b] = flow_result["v_y"][k, a * arrow_boxsize + half, b * arrow_boxsize + half]
+    xs = np.array([a * arrow_boxsize + half for a in range(nbx)], dtype=float) / n_x * x_extent
+    ys = np.array([b * arrow_boxsize + half for b in range(nby)], dtype=float) / n_y * y_extent
+    return xs, ys, sub_x, sub_y

@@ -82,12 +82,15 @@ def main():
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     from oracle import vof_oracle as orc
     OF = import_reference()
-    if "--only-g9" in sys.argv:      # add the vary_regularisation fixture without touching the others
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]   # e.g. --only=g10_ : add one fixture,
+    if "--only-g9" in sys.argv:                                                 # leave the others untouched
+        only.append("g9_")
+    if only:
         np_savez = np.savez
-        def _only_g9(path, *a, **k):
-            if os.path.basename(path).startswith("g9_"):
+        def _only(path, *a, **k):
+            if os.path.basename(path).startswith(tuple(only)):
                 np_savez(path, *a, **k)
-        np.savez = _only_g9
+        np.savez = _only
 
     # ---- G1: the reference's only enabled experiment, AVOF.py:26-50 -------------------
     f1, dx = OF.make_fake_data_frame(x_position=2.5, y_position=2.5, sigma=3, width=5, dimension=50,
@@ -182,6 +185,16 @@ def main():
         scipy.sparse.linalg.spsolve = _real_spsolve
     np.savez(os.path.join(HERE, "g9_vary_regularisation.npz"), movie=movie,
              **{k: np.asarray(v) for k, v in vr.items() if k != "converged"})
+
+    # ---- G10: subsample_velocities_for_visualisation (OF.py:1574-1646) on a random result dict ----
+    rng = np.random.default_rng(10)
+    fr = dict(original_data=rng.random((4, 17, 23)), v_x=rng.standard_normal((3, 17, 23)),
+              v_y=rng.standard_normal((3, 17, 23)), delta_x=0.25)
+    out = dict(v_x=fr["v_x"], v_y=fr["v_y"], delta_x=np.float64(fr["delta_x"]), n_frames=np.int64(4))
+    for box in (1, 2, 3, 4, 5, 7):
+        xp, yp, sx, sy = OF.subsample_velocities_for_visualisation(fr, arrow_boxsize=box)
+        out.update({f"x_positions_{box}": xp, f"y_positions_{box}": yp, f"v_x_{box}": sx, f"v_y_{box}": sy})
+    np.savez(os.path.join(HERE, "g10_subsample.npz"), **out)
 
     # ---- synthetic generator: make_fake_data_frame itself ------------------------------
     fr, dxx = OF.make_fake_data_frame(1.3, 2.9, sigma=1.7, width=6.0, dimension=37, include_noise=False)

@@ -119,3 +119,52 @@ def test_chunked_allgather_reassembles_in_natural_order():
     expect = np.concatenate([np.arange(P * n * n, dtype=np.float64).reshape(P, n, n) + 1000.0 * r for r in range(world)])
     for rank, g in got:
         np.testing.assert_array_equal(g, expect)
+
+
+def _sweep_worker(rank, world, port, n_sa, n_ra, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import vof_oracle as orc
+        from opticalflow_amd.distributed import vary_regularisation_sharded
+        movie = orc.make_texture_stack(16, 3, seed=8)
+        sa, ra = np.linspace(1.0, 3.0, n_sa), np.logspace(1, 3, n_ra)
+        calls = []
+
+        def sweep_fn(mv, a, b, **kw):
+            calls.append((len(a), len(b)))
+            return orc.vary_regularisation(mv, a, b, **kw)
+
+        res = vary_regularisation_sharded(movie, sa, ra, sweep_fn=sweep_fn, delta_x=0.5, delta_t=1.0)
+        q.put((rank, sum(x * y for x, y in calls), {k: res[k] for k in ("speed_means", "remodelling_variances",
+                                                                         "functional", "converged")}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_sa,n_ra", [(2, 3), (1, 1), (3, 1)])
+def test_two_rank_gloo_sharded_parameter_sweep(n_sa, n_ra):
+    """vary_regularisation shards over the (alpha, beta) combinations; one all-reduce of the tables."""
+    from oracle import vof_oracle as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, n_sa, n_ra, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    movie = orc.make_texture_stack(16, 3, seed=8)
+    ref = orc.vary_regularisation(movie, np.linspace(1.0, 3.0, n_sa), np.logspace(1, 3, n_ra), delta_x=0.5, delta_t=1.0)
+    assert sorted(n for _, n, _ in got) == sorted(shard_pair_range(n_sa * n_ra, world, r)[1]
+                                                  - shard_pair_range(n_sa * n_ra, world, r)[0] for r in range(world))
+    for rank, _, res in got:
+        for k in ("speed_means", "remodelling_variances", "functional"):
+            np.testing.assert_allclose(res[k], ref[k], rtol=1e-12, err_msg=k)
+        assert res["converged"].dtype == bool and res["converged"].all() and res["converged"].shape == (n_sa, n_ra)

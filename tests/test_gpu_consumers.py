@@ -1,0 +1,130 @@
+"""GPU tests of the rows next to the hot path: the native (speed_alpha, remodelling_alpha) sweep with its
+device-side mean / variance reductions, the device-resident result mode, and the HIP gather behind
+subsample_velocities_for_visualisation.  Everything goes through the C ABI (libvof.so).
+
+Tolerances: index work (sub-sampling, device-resident vs host result) is bit-exact; the two-pass device reductions agree
+with numpy's pairwise float64 mean / var to 1e-12 relative."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import vof_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def of():
+    from opticalflow_amd import optical_flow
+    return optical_flow
+
+
+def test_native_sweep_equals_per_combination_solves(of):
+    """vof_vary_regularisation_host == looping variational_optical_flow + numpy statistics (OF.py:1974-1983)."""
+    movie = orc.make_texture_stack(40, 4, seed=21)[:, :, :33]
+    sa, ra = np.array([0.5, 2.0]), np.array([20.0, 3000.0])
+    kw = dict(delta_x=0.5, delta_t=2.0, rtol=1e-9, initial_v_x=0.1)
+    r = of.vary_regularisation(movie, sa, ra, return_stats=True, **kw)
+    for i, a in enumerate(sa):
+        for j, b in enumerate(ra):
+            one = of.variational_optical_flow(movie, speed_alpha=a, remodelling_alpha=b, **kw)
+            np.testing.assert_allclose(r["speed_means"][i, j], np.mean(one["speed"]), rtol=1e-12)
+            np.testing.assert_allclose(r["speed_variances"][i, j], np.var(one["speed"]), rtol=1e-12)
+            np.testing.assert_allclose(r["remodelling_means"][i, j], np.mean(one["remodelling"]), rtol=1e-12, atol=1e-18)
+            np.testing.assert_allclose(r["remodelling_variances"][i, j], np.var(one["remodelling"]), rtol=1e-12)
+            np.testing.assert_allclose(r["functional"][i, j], one["L1_functional"] + one["speed_functional"]
+                                       + one["remodelling_functional"], rtol=1e-12)
+            assert r["converged"][i, j] == one["converged"]
+    assert r["stats"]["converged_all"].all() and r["stats"]["max_relative_residual"].max() < 1e-8
+
+
+def test_native_sweep_batches_and_blur(of):
+    """More pairs than fit in one batch (chunk statistics are merged with Chan's formula) and the blur applied once on the
+    device give the same summaries as one batch / the host-side call."""
+    movie = np.round(orc.make_texture_stack(36, 6, seed=22) * 255.0)
+    sa, ra = np.array([1e4]), np.array([1e2, 1e3])
+    kw = dict(smoothing_sigma=1.5, rtol=1e-9)
+    a = of.vary_regularisation(movie, sa, ra, max_pairs_in_flight=2, **kw)
+    b = of.vary_regularisation(movie, sa, ra, max_pairs_in_flight=5, **kw)
+    one = of.variational_optical_flow(movie, speed_alpha=1e4, remodelling_alpha=1e3, **kw)
+    for k in ("speed_means", "speed_variances", "remodelling_means", "remodelling_variances", "functional"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-12, err_msg=k)
+    np.testing.assert_allclose(a["speed_variances"][0, 1], np.var(one["speed"]), rtol=1e-12)
+    np.testing.assert_allclose(a["remodelling_means"][0, 1], np.mean(one["remodelling"]), rtol=1e-12)
+
+
+def test_native_sweep_empty_grid_and_errors(of):
+    movie = orc.make_texture_stack(16, 2, seed=3)
+    r = of.vary_regularisation(movie, np.array([]), np.array([1.0, 2.0]))
+    assert r["speed_means"].shape == (0, 2) and r["converged"].shape == (0, 2)
+    with pytest.raises(TypeError):
+        of.vary_regularisation(movie, np.array([1.0]), np.array([1.0]), no_such_argument=1)
+    with pytest.raises(ValueError):
+        of.vary_regularisation(movie[0], np.array([1.0]), np.array([1.0]))
+
+
+def test_field_moments_are_accurate_with_a_large_offset():
+    """Two-pass reduction: a field with mean 1e6 and unit variance keeps 1e-10 relative accuracy in the variance (a
+    one-pass sum-of-squares formula would lose 4 digits)."""
+    import torch
+    from opticalflow_amd import _native
+    rng = np.random.default_rng(0)
+    x = 1e6 + rng.standard_normal(3 * 50 * 61)
+    ref_mean = float(np.mean(x.astype(np.longdouble)))
+    ref_var = float(np.var(x.astype(np.longdouble)))
+    xd = torch.as_tensor(x, device="cuda:0")
+    torch.cuda.synchronize()
+    with _native.Solver(50, 61, 3) as s:
+        m, v = s.field_moments_dev(xd, x.size)
+    assert m == pytest.approx(ref_mean, rel=1e-15)
+    assert v == pytest.approx(ref_var, rel=1e-10)
+
+
+@pytest.mark.parametrize("box", [1, 2, 3, 4, 5, 7])
+def test_device_subsample_matches_reference_fixture(of, box):
+    """OF.py:1574-1646 on a device-resident result: HIP gather, bit-exact against the reference's output."""
+    import torch
+    g = load_golden("g10_subsample.npz")
+    fr = dict(original_data=torch.zeros((int(g["n_frames"]), 17, 23), dtype=torch.float64, device="cuda:0"),
+              v_x=torch.as_tensor(g["v_x"], device="cuda:0"), v_y=torch.as_tensor(g["v_y"], device="cuda:0"),
+              delta_x=float(g["delta_x"]))
+    out = of.subsample_velocities_for_visualisation(fr, arrow_boxsize=box)
+    for got, key in zip(out, ("x_positions", "y_positions", "v_x", "v_y")):
+        np.testing.assert_array_equal(got, g[f"{key}_{box}"], err_msg=key)
+
+
+def test_device_resident_result_equals_host_result(of):
+    """output="torch": same kernels, no PCIe in between -> bit-identical fields, functionals and flags; the input may be
+    a host array or a device tensor of any real dtype (OF.py:769 casts to float64)."""
+    import torch
+    movie = np.round(orc.make_texture_stack(48, 4, seed=5)[:, :40, :] * 255.0).astype(np.uint8)
+    kw = dict(speed_alpha=50.0, remodelling_alpha=1e3, smoothing_sigma=1.2, delta_x=0.4, delta_t=0.5, max_pairs_in_flight=2)
+    host = of.variational_optical_flow(movie, **kw)
+    for mv in (movie, torch.as_tensor(movie, device="cuda:0")):
+        dev = of.variational_optical_flow(mv, output="torch", **kw)
+        for k in ("v_x", "v_y", "speed", "remodelling", "blurred_data", "original_data"):
+            assert dev[k].is_cuda and dev[k].dtype == torch.float64
+            np.testing.assert_array_equal(dev[k].cpu().numpy(), host[k], err_msg=k)
+        for k in ("L1_functional", "remodelling_functional", "speed_functional", "converged", "delta_x", "delta_t"):
+            assert dev[k] == host[k], k
+    xs, ys, vx, vy = of.subsample_velocities_for_visualisation(dev, arrow_boxsize=5)
+    hx, hy, hvx, hvy = of.subsample_velocities_for_visualisation(host, arrow_boxsize=5)
+    np.testing.assert_array_equal(vx, hvx)
+    np.testing.assert_array_equal(vy, hvy)
+    np.testing.assert_array_equal(xs, hx)
+
+
+def test_result_dictionary_survives_np_save(of, tmp_path):
+    """The reference's scripts store the result with np.save and read it back with np.load(...).item()
+    (AVOF.py:235-238), then hand it to the overlay-movie writer."""
+    import matplotlib
+    matplotlib.use("Agg")
+    g = load_golden("g1_avof_simple_50.npz")
+    res = of.variational_optical_flow(g["movie"], delta_x=float(g["kw_delta_x"]), remodelling_alpha=1e4)
+    fn = str(tmp_path / "result.npy")
+    np.save(fn, res)
+    back = np.load(fn, allow_pickle=True).item()          # our own file
+    assert set(back) == {"v_x", "v_y", "speed", "remodelling", "original_data", "delta_x", "delta_t", "blurred_data",
+                         "converged", "L1_functional", "remodelling_functional", "speed_functional"}
+    np.testing.assert_array_equal(back["v_x"], res["v_x"])
+    of.make_joint_overlay_movie(back, str(tmp_path / "joint.gif"), autoscale=True, arrow_scale=0.5, arrow_boxsize=4, dpi=30)

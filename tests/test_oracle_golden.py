@@ -131,3 +131,16 @@ def test_vary_regularisation_matches_reference():
     for k in ("speed_means", "speed_variances", "remodelling_means", "remodelling_variances", "functional"):
         np.testing.assert_allclose(r[k], g[k], rtol=1e-8, atol=1e-14, err_msg=k)
     assert r["converged"].all() and r["speed_means"].shape == (2, 3)
+
+
+def _g10_result(g):
+    return dict(original_data=np.zeros((int(g["n_frames"]), 17, 23)), v_x=g["v_x"], v_y=g["v_y"], delta_x=float(g["delta_x"]))
+
+
+@pytest.mark.parametrize("box", [1, 2, 3, 4, 5, 7])
+def test_subsample_matches_reference(box):
+    """OF.py:1574-1646 (index work: bit-exact), incl. the half-to-even offsets round(2.5) = 2, round(3.5) = 4."""
+    g = load_golden("g10_subsample.npz")
+    out = orc.subsample_velocities_for_visualisation(_g10_result(g), arrow_boxsize=box)
+    for got, key in zip(out, ("x_positions", "y_positions", "v_x", "v_y")):
+        np.testing.assert_array_equal(got, g[f"{key}_{box}"], err_msg=key)
