@@ -70,6 +70,9 @@ struct vof_ctx {
     // staging for the host-pointer API (allocated lazily)
     double* st_movie = nullptr;
     double* st_out[4] = {nullptr, nullptr, nullptr, nullptr};
+    double* st_out2[4] = {nullptr, nullptr, nullptr, nullptr};   // second output set (copy / solve overlap of the host API)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_solved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     double *blur_tmp = nullptr, *blur_w = nullptr, *blur_io = nullptr;   // Gaussian blur scratch (lazy)
     std::vector<void*> allocs;
     size_t bytes = 0;
@@ -732,6 +735,11 @@ void vof_destroy(vof_ctx* c) {
     if (c->h_active) hipHostFree(c->h_active);
     if (c->h_sc) hipHostFree(c->h_sc);
     if (c->h_func3) hipHostFree(c->h_func3);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_solved[i]) hipEventDestroy(c->ev_solved[i]);
+        if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -838,6 +846,27 @@ int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof
     return 0;
 }
 
+// Device staging of the host API: frames of one batch (+1) and TWO sets of output buffers, so that the device-to-host
+// copies of batch k (copy stream) overlap the solve of batch k+1 (main stream).
+static int ensure_staging(vof_ctx* c, bool double_buffer) {
+    const size_t fs = frame_stride(c);
+    if (!c->st_movie) {
+        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
+        for (int i = 0; i < 4; ++i)
+            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
+    }
+    if (double_buffer && !c->st_out2[0]) {
+        for (int i = 0; i < 4; ++i)
+            if (int rc = dev_alloc(c, &c->st_out2[i], (size_t)c->B * fs)) return rc;
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipEventCreateWithFlags(&c->ev_solved[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+        }
+    }
+    return 0;
+}
+
 int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vof_params* p, double* v_x,
                          double* v_y, double* remodelling, double* speed, vof_pair_stats* stats) {
     if (!c) return -1;
@@ -845,52 +874,66 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
     if (n_frames < 2) { c->err = "need at least two frames"; return -1; }
     if (int rc = check_params(c, p)) return rc;
     HIPCHK(hipSetDevice(c->device));
-    size_t fs = frame_stride(c);
-    if (!c->st_movie) {
-        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
-        for (int i = 0; i < 4; ++i)
-            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
-    }
-    int P = n_frames - 1;
+    const size_t fs = frame_stride(c);
+    const int P = n_frames - 1;
+    const bool multi = P > c->B;                       // more than one batch: overlap copies with the next solve
+    if (int rc = ensure_staging(c, multi)) return rc;
     // Pageable host-to-device copies run at ~2 GB/s on this platform, pinned ones at ~55 GB/s: pin the caller's
     // movie in place for the duration of the call (0.04 s/GB); fall back to the pageable path if that fails.
     const size_t movie_bytes = (size_t)n_frames * fs * sizeof(double);
     const bool pinned = hipHostRegister((void*)movie, movie_bytes, hipHostRegisterDefault) == hipSuccess;
     if (!pinned) (void)hipGetLastError();
     // Freshly allocated output arrays (np.empty) are not resident yet: first-touch page faults would serialise with
-    // the device-to-host copies (0.6 s for 8 GB).  Fault the pages in from helper threads while the GPU solves the
-    // first batch (the arrays are outputs: every byte is overwritten by the copies below).
-    std::vector<std::thread> touchers;
-    {
-        double* outs[4] = {v_x, v_y, remodelling, speed};
-        const size_t out_bytes = (size_t)P * fs * sizeof(double);
-        for (int i = 0; i < 4; ++i)
-            if (outs[i])
-                touchers.emplace_back([ptr = (volatile char*)outs[i], out_bytes]() {
-                    for (size_t o = 0; o < out_bytes; o += 4096) ptr[o] = 0;
-                    if (out_bytes) ptr[out_bytes - 1] = 0;
-                });
-    }
+    // the device-to-host copies (0.6 s for 8 GB).  Helper threads prepare them while the GPU solves the first batch
+    // (the arrays are outputs: every byte is overwritten below): with several batches they are pinned in place
+    // (which faults them in) so that the copies are truly asynchronous; with one batch they are only touched.
+    double* outs[4] = {v_x, v_y, remodelling, speed};
+    const size_t out_bytes = (size_t)P * fs * sizeof(double);
+    bool out_pinned[4] = {false, false, false, false};
+    std::vector<std::thread> helpers;
+    for (int i = 0; i < 4; ++i)
+        if (outs[i])
+            helpers.emplace_back([ptr = (volatile char*)outs[i], out_bytes, multi, dev = c->device, flag = &out_pinned[i]]() {
+                if (multi && hipSetDevice(dev) == hipSuccess &&
+                    hipHostRegister((void*)ptr, out_bytes, hipHostRegisterDefault) == hipSuccess) { *flag = true; return; }
+                for (size_t o = 0; o < out_bytes; o += 4096) ptr[o] = 0;
+                if (out_bytes) ptr[out_bytes - 1] = 0;
+            });
+    auto join_helpers = [&]() { for (auto& t : helpers) if (t.joinable()) t.join(); };
     int rc_all = 0;
-    for (int k0 = 0; k0 < P && !rc_all; k0 += c->B) {
-        int np = std::min(c->B, P - k0);
+    int batch = 0;
+    for (int k0 = 0; k0 < P && !rc_all; k0 += c->B, ++batch) {
+        const int np = std::min(c->B, P - k0);
+        const int set = multi ? (batch & 1) : 0;
+        double** so = set ? c->st_out2 : c->st_out;
         hipError_t e = hipMemcpyAsync(c->st_movie, movie + (size_t)k0 * fs, (size_t)(np + 1) * fs * sizeof(double),
                                       hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { c->err = std::string("H2D copy failed: ") + hipGetErrorString(e); rc_all = -2; break; }
-        int rc = solve_batch(c, c->st_movie, np, c->st_out[0], c->st_out[1], c->st_out[2], c->st_out[3],
-                             stats ? stats + k0 : nullptr);
+        if (multi && batch >= 2) {                     // this output set is free once its previous copies are done
+            if (hipStreamWaitEvent(c->stream, c->ev_copied[set], 0) != hipSuccess) { c->err = "stream wait failed"; rc_all = -2; break; }
+        }
+        int rc = solve_batch(c, c->st_movie, np, so[0], so[1], so[2], so[3], stats ? stats + k0 : nullptr);
         if (rc) { rc_all = rc; break; }
-        for (auto& t : touchers) if (t.joinable()) t.join();
-        double* dst[4] = {v_x, v_y, remodelling, speed};
+        join_helpers();
+        hipStream_t cs = multi ? c->copy_stream : c->stream;
+        if (multi) {
+            if (hipEventRecord(c->ev_solved[set], c->stream) != hipSuccess ||
+                hipStreamWaitEvent(cs, c->ev_solved[set], 0) != hipSuccess) { c->err = "event record failed"; rc_all = -2; break; }
+        }
         for (int i = 0; i < 4 && !rc_all; ++i)
-            if (dst[i]) {
-                e = hipMemcpyAsync(dst[i] + (size_t)k0 * fs, c->st_out[i], (size_t)np * fs * sizeof(double),
-                                   hipMemcpyDeviceToHost, c->stream);
+            if (outs[i]) {
+                e = hipMemcpyAsync(outs[i] + (size_t)k0 * fs, so[i], (size_t)np * fs * sizeof(double), hipMemcpyDeviceToHost, cs);
                 if (e != hipSuccess) { c->err = std::string("D2H copy failed: ") + hipGetErrorString(e); rc_all = -2; }
             }
-        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc_all) { c->err = "stream synchronize failed"; rc_all = -2; }
+        if (multi) {
+            if (!rc_all && hipEventRecord(c->ev_copied[set], cs) != hipSuccess) { c->err = "event record failed"; rc_all = -2; }
+        } else if (hipStreamSynchronize(c->stream) != hipSuccess && !rc_all) { c->err = "stream synchronize failed"; rc_all = -2; }
     }
-    for (auto& t : touchers) if (t.joinable()) t.join();
+    join_helpers();
+    if (multi && hipStreamSynchronize(c->copy_stream) != hipSuccess && !rc_all) { c->err = "copy stream synchronize failed"; rc_all = -2; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc_all) { c->err = "stream synchronize failed"; rc_all = -2; }
+    for (int i = 0; i < 4; ++i)
+        if (out_pinned[i]) (void)hipHostUnregister((void*)outs[i]);
     if (pinned) (void)hipHostUnregister((void*)movie);
     return rc_all;
 }
@@ -1006,11 +1049,7 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
     HIPCHK(hipSetDevice(c->device));
     const size_t fs = frame_stride(c);
     const int P = n_frames - 1;
-    if (!c->st_movie) {   // per-batch output staging shared with the host API
-        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
-        for (int i = 0; i < 4; ++i)
-            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
-    }
+    if (int rc = ensure_staging(c, false)) return rc;   // per-batch output staging shared with the host API
     // the whole movie stays resident for the sweep (freed on return)
     double* dmovie = nullptr;
     HIPCHK(hipMalloc((void**)&dmovie, (size_t)n_frames * fs * sizeof(double)));
@@ -1157,11 +1196,7 @@ int vof_debug_setup(vof_ctx* c, const double* movie_host, int n_pairs, const vof
     if (int rc = check_params(c, p)) return rc;
     HIPCHK(hipSetDevice(c->device));
     size_t fs = frame_stride(c);
-    if (!c->st_movie) {
-        if (int rc = dev_alloc(c, &c->st_movie, (size_t)(c->B + 1) * fs)) return rc;
-        for (int i = 0; i < 4; ++i)
-            if (int rc = dev_alloc(c, &c->st_out[i], (size_t)c->B * fs)) return rc;
-    }
+    if (int rc = ensure_staging(c, false)) return rc;
     HIPCHK(hipMemcpyAsync(c->st_movie, movie_host, (size_t)(n_pairs + 1) * fs * sizeof(double), hipMemcpyHostToDevice,
                           c->stream));
     if (int rc = setup_batch(c, c->st_movie, n_pairs)) return rc;

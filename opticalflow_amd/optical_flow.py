@@ -77,11 +77,11 @@ def apply_constant_boundary_condition(image):
     image[:, -1] = image[:, -3]
 
 
-def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=96):
+def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=128):
     """Largest batch of frame pairs whose workspace fits in ``memory_fraction`` of the free HBM."""
     free, _total = _native.device_memory(device)
     budget = free * memory_fraction
-    per_pair = _native.query_workspace(n_i, n_j, 1) + 5 * n_i * n_j * 8  # + host-API staging
+    per_pair = _native.query_workspace(n_i, n_j, 1) + 9 * n_i * n_j * 8  # + host-API staging (two output sets)
     return int(max(1, min(n_pairs, cap, budget // max(per_pair, 1))))
 
 
