@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 102 /* 0.1.2 */
+#define VOF_VERSION 103 /* 0.1.3 */
 
 typedef struct vof_ctx vof_ctx;
 
@@ -48,6 +48,14 @@ typedef struct vof_params {
     int32_t nu_post_coarse;
     int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 w_cycle_visits times per cycle (a one-level W-cycle); -1: V-cycle */
     int32_t w_cycle_visits;    /* visits of level w_cycle_level + 1 per cycle (default 3); 0 = 2 */
+    int32_t krylov_method;     /* 0: BiCGStab only (the reference's KSP type 'bcgs', OF.py:1081); 1: restarted GMRES only;
+                                  2 (default): BiCGStab, then GMRES(gmres_restart) for the pairs that have not met the
+                                  stopping rule after fallback_after iterations or broke down.  Same preconditioner,
+                                  same stopping rule; `iterations` counts the Krylov steps of both phases */
+    int32_t gmres_restart;     /* restart length (default 100, at most 128); the basis takes (restart + 1) float64 vectors per pair in
+                                  flight and is capped at half of the free device memory when the fallback first runs */
+    int32_t fallback_after;    /* BiCGStab iterations before the fallback (default 8) */
+    int32_t reserved;
 } vof_params;
 
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */

@@ -74,6 +74,13 @@ struct vof_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_solved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     double *blur_tmp = nullptr, *blur_w = nullptr, *blur_io = nullptr;   // Gaussian blur scratch (lazy)
+    // GMRES fallback (allocated on first use): basis vectors V_0..V_m (each B * len0), per-pair state, partials, flags
+    double* gm_V = nullptr;
+    GmresState* gm_state = nullptr;
+    double* gm_partials = nullptr;
+    int* gm_cycle = nullptr;
+    int gm_m = 0;
+    long long gmres_pairs = 0;   // pairs handed to the fallback since the context was created
     std::vector<void*> allocs;
     size_t bytes = 0;
     std::string err;
@@ -550,6 +557,118 @@ int setup_batch(vof_ctx* c, const double* frames_dev, int np) {
 
 inline dim3 rgrid(const vof_ctx* c, int np) { return dim3(c->nblk, np, 1); }
 
+// Number of active pairs (copies the flags to the host; synchronises the stream).
+int count_active(vof_ctx* c, int np) {
+    if (hipMemcpyAsync(c->h_active, c->active, np * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    int n = 0;
+    for (int k = 0; k < np; ++k) n += c->h_active[k] != 0;
+    return n;
+}
+
+// Buffers of the GMRES fallback: restart length = min(requested, what fits in half of the free device memory).
+int gmres_buffers(vof_ctx* c, int want_m) {
+    want_m = std::min(want_m, GM_MAXM);
+    if (c->gm_V) return 0;   // allocated once per context
+    const size_t vec = (size_t)c->B * 3 * c->L[0].npts * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t fixed = (size_t)c->B * (sizeof(GmresState) + (GM_NV + 1) * c->nblk * sizeof(double) + sizeof(int));
+    const double budget = 0.5 * (double)free_b - (double)fixed;
+    int fit = budget > 0 ? (int)std::min<double>(budget / (double)vec, 1e6) - 1 : 0;
+    int m = std::min(want_m, fit);
+    if (m < 4) { c->err = "not enough device memory for the GMRES fallback (lower max_pairs_in_flight)"; return -3; }
+    if (int rc = dev_alloc(c, &c->gm_V, (size_t)(m + 1) * c->B * 3 * c->L[0].npts)) return rc;
+    if (int rc = dev_alloc(c, &c->gm_state, (size_t)c->B)) return rc;
+    if (int rc = dev_alloc(c, &c->gm_partials, (size_t)c->B * (GM_NV + 1) * c->nblk)) return rc;
+    c->gm_m = m;
+    return 0;
+}
+
+// Restarted, right-preconditioned GMRES on the pairs that are not converged yet: x = x_0 + M (V_k y), M = one
+// multigrid cycle (float64 vectors), restart from the true residual b - A x.  `iterations` keeps counting Krylov steps
+// (one cycle application each) on top of the BiCGStab iterations already spent.
+int gmres_phase(vof_ctx* c, int np) {
+    const vof_params& P = c->prm;
+    hipStream_t s = c->stream;
+    const size_t len = 3 * c->L[0].npts;
+    const size_t vstride = (size_t)c->B * len;
+    if (!c->gm_cycle) {   // flags are needed before the (large) basis is
+        if (int rc = dev_alloc(c, &c->gm_cycle, (size_t)c->B)) return rc;
+    }
+    k_gm_begin<<<(np + 63) / 64, 64, 0, s>>>(c->sc, c->active, c->gm_cycle, np, P.max_iterations);
+    int nact = count_active(c, np);
+    if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
+    if (nact == 0) return 0;
+    if (!c->gm_V) {
+        int rc = gmres_buffers(c, P.gmres_restart > 0 ? P.gmres_restart : 100);
+        if (rc == -3) { c->err.clear(); return 0; }   // no room: leave the pairs unconverged (reported per pair)
+        if (rc) return rc;
+    }
+    c->gmres_pairs += nact;
+    const int m = std::min(c->gm_m, P.gmres_restart > 0 ? P.gmres_restart : 100);
+    c->vfloat = false;   // float64 cycle vectors: the basis vectors are the cycle's right-hand sides
+    double* V = c->gm_V;
+    double* w = c->kt;
+    const dim3 rg = rgrid(c, np);
+    const int coef_c = (int)(offsetof(GmresState, c) / sizeof(double)), coef_y = (int)(offsetof(GmresState, y) / sizeof(double));
+    for (;;) {
+        c->cur_units = nact;
+        int nb = residual_d(c, c->kx, c->kb, V, np, c->gm_cycle, 1);      // V_0 = b - A x and its norm
+        if (!nb) { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rg, RBLK, 0, s>>>(V, V, nullptr, nullptr, len, c->partials, c->gm_cycle); nb = c->nblk; }
+        { Prof p(c, VOF_K_VECTOR, 0);
+          k_gm_init<<<np, 64, 0, s>>>(c->gm_state, c->sc, c->partials, nb, c->active, c->gm_cycle, P.max_iterations); }
+        nact = count_active(c, np);
+        if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
+        if (nact == 0) break;
+        c->cur_units = nact;
+        { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len); k_gm_scale<<<rg, RBLK, 0, s>>>(V, V, len, c->gm_state, c->active); }
+        int jdone = 0;
+        for (int j = 0; j < m; ++j) {
+            const int* act = c->active;
+            vcycle(c, c->ky, V + (size_t)j * vstride, np, act);             // z = M v_j
+            krylov_apply(c, c->ky, w, np, act);                              // w = A z
+            for (int pass = 0; pass < 2; ++pass) {                           // classical Gram-Schmidt, twice
+                for (int i0 = 0; i0 <= j; i0 += GM_NV) {
+                    int cnt = std::min(GM_NV, j + 1 - i0);
+                    Prof p(c, VOF_K_REDUCE, 0, 8.0 * len * (cnt + 1));
+                    k_gm_multidot<<<rg, RBLK, 0, s>>>(V + (size_t)i0 * vstride, vstride, cnt, w, len, c->gm_partials, act);
+                    k_gm_hcoef<<<np, 64, 0, s>>>(c->gm_state, c->gm_partials, c->nblk, i0, cnt, pass, act);
+                }
+                for (int i0 = 0; i0 <= j; i0 += GM_NV) {
+                    int cnt = std::min(GM_NV, j + 1 - i0);
+                    bool last = pass == 1 && i0 + GM_NV > j;                 // last chunk: write v_{j+1} (unnormalised) + norm
+                    Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * (cnt + 2));
+                    k_gm_axpy<<<rg, RBLK, 0, s>>>(V + (size_t)i0 * vstride, vstride, i0, cnt, c->gm_state, coef_c, -1.0, w,
+                                                  last ? V + (size_t)(j + 1) * vstride : w, len, act, 0,
+                                                  last ? c->gm_partials : nullptr);
+                }
+            }
+            { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len);
+              k_gm_givens<<<np, 64, 0, s>>>(c->gm_state, c->sc, c->gm_partials, c->nblk, j, c->active, P.max_iterations);
+              k_gm_scale<<<rg, RBLK, 0, s>>>(V + (size_t)(j + 1) * vstride, V + (size_t)(j + 1) * vstride, len, c->gm_state, c->active); }
+            jdone = j + 1;
+            nact = count_active(c, np);
+            if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
+            if (nact == 0) break;
+            c->cur_units = nact;
+        }
+        // x += M (V_k y) for every pair of this cycle
+        { Prof p(c, VOF_K_VECTOR, 0); k_gm_solve_y<<<(np + 63) / 64, 64, 0, s>>>(c->gm_state, c->gm_cycle, np); }
+        for (int i0 = 0; i0 < jdone; i0 += GM_NV) {
+            int cnt = std::min(GM_NV, jdone - i0);
+            Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * (cnt + 2));
+            k_gm_axpy<<<rg, RBLK, 0, s>>>(V + (size_t)i0 * vstride, vstride, i0, cnt, c->gm_state, coef_y, 1.0,
+                                          i0 ? c->kp : nullptr, c->kp, len, c->gm_cycle, 1, nullptr);
+        }
+        vcycle(c, c->ky, c->kp, np, c->gm_cycle);
+        { Prof p(c, VOF_K_VECTOR, 0, 24.0 * len); k_gm_xpy<<<rg, RBLK, 0, s>>>(c->kx, c->ky, len, c->gm_cycle); }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double* vy, double* gm, double* speed,
                 vof_pair_stats* stats) {
     const vof_params& P = c->prm;
@@ -580,7 +699,10 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kr, nullptr, nullptr, len, c->partials, nullptr); }
     { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R0><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
 
-    for (int it = 0; it < P.max_iterations; ++it) {
+    // krylov_method: 0 = BiCGStab only (the reference's 'bcgs'); 1 = GMRES only; 2 = BiCGStab, and restarted GMRES for
+    // the pairs that have not met the tolerance after `fallback_after` iterations (or broke down)
+    const int bicg_limit = P.krylov_method == 1 ? 0 : (P.krylov_method == 2 ? std::min(P.max_iterations, P.fallback_after) : P.max_iterations);
+    for (int it = 0; it < bicg_limit; ++it) {
         HIPCHK(hipMemcpyAsync(c->h_active, c->active, np * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         int nact = 0;
@@ -614,6 +736,8 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
           VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, (const VT*)c->kz, c->kr, c->kt, c->krh, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
+    if (P.krylov_method != 0)
+        if (int rc = gmres_phase(c, np)) return rc;
     // independent residual (OF.py:1150-1151)
     c->cur_units = np;
     int nb3 = residual_d(c, c->kx, c->kb, c->kt, np, nullptr, 1);
@@ -654,6 +778,9 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
     if (p->vcycle_precision < 0 || p->vcycle_precision > 2) { c->err = "vcycle_precision must be 0, 1 or 2"; return -1; }
+    if (p->krylov_method < 0 || p->krylov_method > 2) { c->err = "krylov_method must be 0, 1 or 2"; return -1; }
+    if (p->gmres_restart < 0 || p->gmres_restart > GM_MAXM) { c->err = "gmres_restart must be in [0, 128]"; return -1; }
+    if (p->fallback_after < 0) { c->err = "fallback_after must be >= 0"; return -1; }
     c->prm = *p;
     // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
     c->vfloat = p->vcycle_precision >= 1 && c->fused && c->L.size() > 1;
@@ -685,6 +812,9 @@ void vof_default_params(vof_params* p) {
     p->reference_quirks = 1;
     p->coarse_precision = 1;       // float32 storage of the Galerkin stencils (preconditioner only)
     p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)
+    p->krylov_method = 2;          // BiCGStab (the reference's 'bcgs'); stragglers are finished by restarted GMRES
+    p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
+    p->fallback_after = 8;         // BiCGStab iterations before the fallback (the benchmark workloads need 3-5)
 }
 
 const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

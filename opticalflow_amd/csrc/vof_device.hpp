@@ -926,6 +926,209 @@ __global__ void k_sum3(const double* __restrict__ partials, int nblk, double* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Restarted GMRES (right-preconditioned by the multigrid cycle), the fallback Krylov method for pairs BiCGStab does not
+// bring below the tolerance (in the grad-div dominated regimes the preconditioned operator has a few
+// dozen outlying eigenvalues; the minimal-residual method needs about half the cycles of BiCGStab there and converges
+// where BiCGStab stagnates).  All pairs advance in lockstep; the small per-pair least-squares problem (Givens-rotated
+// Hessenberg matrix) lives on the device.  Orthogonalisation: classical Gram-Schmidt, applied twice (CGS2), GM_NV basis
+// vectors per pass over w.
+// ------------------------------------------------------------------------------------------
+constexpr int GM_MAXM = 128;   // largest restart length
+constexpr int GM_NV = 8;       // basis vectors per multi-dot / multi-axpy launch
+
+struct GmresState {
+    double R[GM_MAXM * GM_MAXM];   // rotated Hessenberg matrix, column j at R + j * GM_MAXM (upper triangular)
+    double cs[GM_MAXM], sn[GM_MAXM];
+    double g[GM_MAXM + 1];         // rotated right-hand side; |g[k]| = residual norm after k steps
+    double y[GM_MAXM];             // solution of the k x k triangular system
+    double h[GM_MAXM + 2];         // current Hessenberg column (before the rotations)
+    double c[GM_MAXM + 2];         // coefficients of the current Gram-Schmidt pass
+    double scale;                  // 1 / norm of the vector to normalise next
+    int k;                         // columns built in this cycle
+    int pad;
+};
+
+// active = cycle = pair still to be solved (not converged, iterations left); clears stale BiCGStab breakdown flags
+__global__ void k_gm_begin(PairScalars* __restrict__ sc, int* __restrict__ active, int* __restrict__ cycle, int np, int max_it) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= np) return;
+    int on = (!sc[pair].converged && sc[pair].iterations < max_it && sc[pair].bnorm2 > 0.0) ? 1 : 0;
+    active[pair] = on;
+    cycle[pair] = on;
+}
+
+// start of a cycle: true residual norm (partials slot 0) -> convergence test, g[0], normalisation factor
+__global__ void k_gm_init(GmresState* __restrict__ st, PairScalars* __restrict__ sc, const double* __restrict__ partials,
+                          int nblk, int* __restrict__ active, int* __restrict__ cycle, int max_it) {
+    int pair = blockIdx.x;
+    if (!cycle[pair]) return;
+    double rn2 = sum_partials(partials + (size_t)pair * 3 * nblk, nblk);
+    if (threadIdx.x != 0) return;
+    PairScalars& s = sc[pair];
+    s.rnorm2 = rn2;
+    s.breakdown = 0;
+    if (rn2 <= s.tol2) { s.converged = 1; active[pair] = 0; cycle[pair] = 0; return; }
+    if (s.iterations >= max_it || !isfinite(rn2)) { active[pair] = 0; cycle[pair] = 0; return; }
+    GmresState& q = st[pair];
+    double beta = sqrt(rn2);
+    q.g[0] = beta;
+    q.scale = 1.0 / beta;
+    q.k = 0;
+    active[pair] = 1;
+}
+
+// dst = src * state.scale
+__global__ __launch_bounds__(RBLK) void k_gm_scale(double* __restrict__ dst, const double* __restrict__ src, size_t len,
+                                                   const GmresState* __restrict__ st, const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    const double f = st[pair].scale;
+    size_t off = (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) dst[off + i] = src[off + i] * f;
+}
+
+// partials[pair][k][blk] = (V_k, w) for k < cnt, slot GM_NV = (w, w); V_k = V + k * vstride
+__global__ __launch_bounds__(RBLK) void k_gm_multidot(const double* __restrict__ V, size_t vstride, int cnt,
+                                                      const double* __restrict__ w, size_t len,
+                                                      double* __restrict__ partials, const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    const double* wp = w + (size_t)pair * len;
+    const double* vp = V + (size_t)pair * len;
+    double acc[GM_NV + 1];
+#pragma unroll
+    for (int k = 0; k <= GM_NV; ++k) acc[k] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+        double wv = wp[i];
+#pragma unroll
+        for (int k = 0; k < GM_NV; ++k)
+            if (k < cnt) acc[k] += vp[(size_t)k * vstride + i] * wv;
+        acc[GM_NV] += wv * wv;
+    }
+    __shared__ double sh[GM_NV + 1][RBLK / 64];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k <= GM_NV; ++k) {
+        double v = wave_sum(acc[k]);
+        if (lane == 0) sh[k][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= GM_NV) {
+        double t = 0;
+        for (int i = 0; i < RBLK / 64; ++i) t += sh[threadIdx.x][i];
+        partials[((size_t)pair * (GM_NV + 1) + threadIdx.x) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// reduce the multidot partials: pass 0 sets h[i0 + k] = c[k] = dot, pass 1 (re-orthogonalisation) adds the correction
+__global__ void k_gm_hcoef(GmresState* __restrict__ st, const double* __restrict__ partials, int nblk, int i0, int cnt,
+                           int pass, const int* __restrict__ active) {
+    int pair = blockIdx.x;
+    if (!active[pair]) return;
+    for (int k = 0; k < cnt; ++k) {
+        double v = sum_partials(partials + ((size_t)pair * (GM_NV + 1) + k) * nblk, nblk);
+        if (threadIdx.x == 0) {
+            GmresState& q = st[pair];
+            q.c[i0 + k] = v;
+            q.h[i0 + k] = pass ? q.h[i0 + k] + v : v;
+        }
+    }
+}
+
+// w_out = w_in (or 0) + sign * sum_{k < cnt} coef[k] V_k; coef = per-pair array inside the state (offset in doubles);
+// limit_by_k: only the first state.k - i0 vectors of this chunk exist for the pair.  Optionally ||w_out||^2 partials (slot 0).
+__global__ __launch_bounds__(RBLK) void k_gm_axpy(const double* __restrict__ V, size_t vstride, int i0, int cnt,
+                                                  const GmresState* __restrict__ st, int coef_offset, double sign,
+                                                  const double* w_in, double* w_out, size_t len,
+                                                  const int* __restrict__ active, int limit_by_k,
+                                                  double* __restrict__ norm_partials) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    const double* coef = reinterpret_cast<const double*>(st + pair) + coef_offset + i0;
+    int n = cnt;
+    if (limit_by_k) n = min(cnt, st[pair].k - i0);
+    double cf[GM_NV];
+#pragma unroll
+    for (int k = 0; k < GM_NV; ++k) cf[k] = (k < n) ? sign * coef[k] : 0.0;
+    const double* vp = V + (size_t)pair * len;
+    size_t off = (size_t)pair * len;
+    double nrm = 0.0;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+        double a = w_in ? w_in[off + i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < GM_NV; ++k)
+            if (k < n) a += cf[k] * vp[(size_t)k * vstride + i];
+        w_out[off + i] = a;
+        nrm += a * a;
+    }
+    if (norm_partials) {
+        __shared__ double sh[RBLK / 64];
+        double v = wave_sum(nrm);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0;
+            for (int i = 0; i < RBLK / 64; ++i) t += sh[i];
+            norm_partials[((size_t)pair * (GM_NV + 1)) * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
+// step j: h[j+1] = ||w||, rotate the new column, update g, test the residual estimate |g[j+1]|
+__global__ void k_gm_givens(GmresState* __restrict__ st, PairScalars* __restrict__ sc, const double* __restrict__ partials,
+                            int nblk, int j, int* __restrict__ active, int max_it) {
+    int pair = blockIdx.x;
+    if (!active[pair]) return;
+    double hn2 = sum_partials(partials + ((size_t)pair * (GM_NV + 1)) * nblk, nblk);
+    if (threadIdx.x != 0) return;
+    GmresState& q = st[pair];
+    PairScalars& s = sc[pair];
+    double hn = sqrt(hn2);
+    q.h[j + 1] = hn;
+    for (int i = 0; i < j; ++i) {
+        double a = q.cs[i] * q.h[i] + q.sn[i] * q.h[i + 1];
+        q.h[i + 1] = -q.sn[i] * q.h[i] + q.cs[i] * q.h[i + 1];
+        q.h[i] = a;
+    }
+    double d = hypot(q.h[j], q.h[j + 1]);
+    double cs = d > 0.0 ? q.h[j] / d : 1.0, sn = d > 0.0 ? q.h[j + 1] / d : 0.0;
+    q.cs[j] = cs; q.sn[j] = sn;
+    q.h[j] = d;
+    q.g[j + 1] = -sn * q.g[j];
+    q.g[j] = cs * q.g[j];
+    for (int i = 0; i <= j; ++i) q.R[(size_t)j * GM_MAXM + i] = q.h[i];
+    q.k = j + 1;
+    q.scale = hn > 0.0 ? 1.0 / hn : 0.0;
+    s.rnorm2 = q.g[j + 1] * q.g[j + 1];
+    s.iterations += 1;
+    // the estimate equals the true residual norm in exact arithmetic; the next cycle starts from the true residual
+    if (s.rnorm2 <= s.tol2 || !(hn > 0.0) || !(d > 0.0) || s.iterations >= max_it || !isfinite(s.rnorm2)) active[pair] = 0;
+}
+
+// y = R^{-1} g for the k columns built in this cycle
+__global__ void k_gm_solve_y(GmresState* __restrict__ st, const int* __restrict__ cycle, int np) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= np || !cycle[pair]) return;
+    GmresState& q = st[pair];
+    int k = q.k;
+    for (int i = k - 1; i >= 0; --i) {
+        double v = q.g[i];
+        for (int m = i + 1; m < k; ++m) v -= q.R[(size_t)m * GM_MAXM + i] * q.y[m];
+        double dgl = q.R[(size_t)i * GM_MAXM + i];
+        q.y[i] = dgl != 0.0 ? v / dgl : 0.0;
+    }
+}
+
+// x += z (z V-cycle output, float64)
+__global__ __launch_bounds__(RBLK) void k_gm_xpy(double* __restrict__ x, const double* __restrict__ z, size_t len,
+                                                 const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    size_t off = (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) x[off + i] += z[off + i];
+}
+
 // Shifted power sums of a field, sum (x - shift) and sum (x - shift)^2, for the mean / variance summaries of
 // vary_regularisation (OF.py:1978-1981: np.mean / np.var of the speed and remodelling stacks).  Two passes (shift = 0,
 // then shift = mean) give the variance without cancellation; partials are combined in fixed order by k_sum3.

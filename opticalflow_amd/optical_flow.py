@@ -87,7 +87,7 @@ def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap
 
 def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                    use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
-                   multigrid_sweeps, w_cycle_level):
+                   multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None):
     """vof_params from the keyword arguments of ``variational_optical_flow``."""
     if rtol is None:
         rtol = 1e-11 if use_direct_solver else 1e-6
@@ -108,6 +108,9 @@ def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x
             params.w_cycle_level, params.w_cycle_visits = int(w_cycle_level[0]), int(w_cycle_level[1])
         else:
             params.w_cycle_level = int(w_cycle_level)
+    params.krylov_method = {"bicgstab": 0, "gmres": 1, "auto": 2}[krylov_method]
+    if gmres_restart is not None:
+        params.gmres_restart = int(gmres_restart)
     return params
 
 
@@ -131,6 +134,8 @@ def variational_optical_flow(movie,
                              vcycle_precision="float64",
                              multigrid_sweeps=None,
                              w_cycle_level=None,
+                             krylov_method="auto",
+                             gmres_restart=None,
                              verbose=False,
                              return_stats=False,
                              output="numpy",
@@ -158,6 +163,9 @@ def variational_optical_flow(movie,
         stopping rule and the result are float64 either way), ``multigrid_sweeps``
         (block-GS sweeps per V-cycle: ``(pre, post)`` on level 0 and optionally ``(pre, post)`` on the coarse levels),
         ``w_cycle_level`` (-1: V-cycle; ``l``: level ``l`` visits level ``l+1`` twice per cycle),
+        ``krylov_method`` ("bicgstab": the reference's KSP type, OF.py:1081; "gmres": restarted GMRES with the same
+        preconditioner and stopping rule; "auto" (default): BiCGStab, and GMRES(``gmres_restart``, default 100) for the
+        pairs that have not converged after 8 iterations - the grad-div dominated regimes),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals), ``output`` ("numpy": host arrays as in the reference; "torch": ``movie`` may be a
         torch tensor already on the device and every array of the result stays on the device as a float64 torch
@@ -169,7 +177,7 @@ def variational_optical_flow(movie,
                                                     speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y,
                                                     initial_remodelling, use_direct_solver, rtol, max_iterations,
                                                     reference_quirks, coarse_precision, vcycle_precision, multigrid_sweeps,
-                                                    w_cycle_level), delta_x, delta_t)
+                                                    w_cycle_level, krylov_method, gmres_restart), delta_x, delta_t)
     if output != "numpy":
         raise ValueError("output must be 'numpy' or 'torch'")
     movie = np.asarray(movie).astype(np.float64)                       # OF.py:769
@@ -184,7 +192,7 @@ def variational_optical_flow(movie,
         raise ValueError("movie needs at least two frames")
     params = _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                             use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
-                            multigrid_sweeps, w_cycle_level)
+                            multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart)
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()
@@ -287,7 +295,7 @@ def vary_regularisation(movie,
     kw = dict(delta_x=1.0, delta_t=1.0, smoothing_sigma=None, initial_v_x=0.0, initial_v_y=0.0, initial_remodelling=0.0,
               use_direct_solver=False, rtol=None, max_iterations=1000, reference_quirks=True, device=0,
               max_pairs_in_flight=None, coarse_precision="float32", vcycle_precision="float64", multigrid_sweeps=None,
-              w_cycle_level=None, verbose=False, return_stats=False)
+              w_cycle_level=None, krylov_method="auto", gmres_restart=None, verbose=False, return_stats=False)
     for k in kwargs:
         if k not in kw:
             raise TypeError(f"variational_optical_flow() got an unexpected keyword argument {k!r}")
@@ -295,7 +303,7 @@ def vary_regularisation(movie,
     params = _solver_params(1.0, 1.0, kw["delta_x"], kw["delta_t"], kw["initial_v_x"], kw["initial_v_y"],
                             kw["initial_remodelling"], kw["use_direct_solver"], kw["rtol"], kw["max_iterations"],
                             kw["reference_quirks"], kw["coarse_precision"], kw["vcycle_precision"],
-                            kw["multigrid_sweeps"], kw["w_cycle_level"])
+                            kw["multigrid_sweeps"], kw["w_cycle_level"], kw["krylov_method"], kw["gmres_restart"])
     taps = None if kw["smoothing_sigma"] is None else gaussian_taps(kw["smoothing_sigma"])
     pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, T - 1, kw["device"])
     with _native.Solver(N_i, N_j, pairs, device=kw["device"]) as solver:

@@ -269,3 +269,48 @@ def test_full_size_properties_1024(of):
     assert abs(np.mean(res["remodelling"])) < 5e-3
     again = of.variational_optical_flow(movie, remodelling_alpha=1e4)
     np.testing.assert_array_equal(again["v_x"], res["v_x"])          # bit-reproducible
+
+
+@pytest.mark.parametrize("name", ["g1_avof_simple_50.npz", "g3_stack_32x48x4.npz", "g6_8bit_64.npz", "g7_texture_64x3.npz"])
+def test_gmres_reaches_the_reference_solution(of, name):
+    """krylov_method='gmres' (the fallback method, used alone): same preconditioner and stopping rule, so the converged
+    answer is the exact solution of the reference-assembled system to the tight tolerance."""
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    res = of.variational_optical_flow(g["movie"], rtol=1e-10, krylov_method="gmres", return_stats=True, **kw)
+    assert res["stats"]["converged"].all() and res["stats"]["relative_residual"].max() < 1e-9
+    check_fields(res, g, 1e-6 if "8bit" in name else TIGHT)
+    short = of.variational_optical_flow(g["movie"], rtol=1e-10, krylov_method="gmres", gmres_restart=5, return_stats=True, **kw)
+    assert short["stats"]["converged"].all()                      # restarts: x_0 + M V y accumulated over several cycles
+    check_fields(short, g, 1e-6 if "8bit" in name else TIGHT)
+
+
+def test_gmres_fallback_finishes_what_bicgstab_starts(of):
+    """8-bit data without blur, alpha / I^2 ~ 0.15 (the grad-div dominated regime): BiCGStab needs
+    > 100 iterations at 258^2; the default hands the pairs to GMRES after 8 iterations, which converges in about a
+    quarter of the multigrid cycles.  Both satisfy the reference's stopping rule (checked on the CPU) and agree to
+    the accuracy that rule implies."""
+    movie = np.round(orc.make_texture_stack(258, 3, seed=1) * 255.0)
+    kw = dict(speed_alpha=1e4, remodelling_alpha=1e2, return_stats=True)
+    auto = of.variational_optical_flow(movie, **kw)
+    bicg = of.variational_optical_flow(movie, krylov_method="bicgstab", **kw)
+    for r in (auto, bicg):
+        assert r["stats"]["converged"].all() and r["stats"]["relative_residual"].max() <= 1.5e-6
+    cycles_auto = 2 * 8 + (auto["stats"]["iterations"] - 8)      # BiCGStab: two cycles per iteration, GMRES: one
+    assert (cycles_auto < 2 * bicg["stats"]["iterations"]).all()
+    assert auto["stats"]["iterations"].max() <= 120
+    xi = np.stack([auto["v_x"][0], auto["v_y"][0], auto["remodelling"][0]])[:, 1:-1, 1:-1]
+    b = orc.rhs_interior(movie[0], movie[1])
+    rr = np.linalg.norm(b - orc.apply_operator_interior(movie[0], xi, 1e4, 1e2)) / np.linalg.norm(b)
+    assert rr <= 1.5e-6
+    check_fields(auto, bicg, LOOSE)
+
+
+def test_easy_regimes_never_touch_the_fallback(of):
+    """The benchmark regime converges in a handful of BiCGStab iterations: 'auto' and 'bicgstab' are bit-identical."""
+    movie = orc.make_texture_stack(96, 4, seed=2)
+    a = of.variational_optical_flow(movie, remodelling_alpha=1e4, return_stats=True)
+    b = of.variational_optical_flow(movie, remodelling_alpha=1e4, krylov_method="bicgstab", return_stats=True)
+    assert a["stats"]["iterations"].max() <= 8
+    np.testing.assert_array_equal(a["v_x"], b["v_x"])
+    np.testing.assert_array_equal(a["stats"]["iterations"], b["stats"]["iterations"])
