@@ -54,20 +54,27 @@ def main():
         by_sym = defaultdict(list)
         for key, n, rd, wr in rows:
             by_sym[key[0]].append((key[1], n, rd, wr))
-        names = {"k_sweep<vof::SweepFine": ("gs0", 0), "k_sweep<vof::SweepStored": ("gs", 1),
-                 "k_stream_apply0": ("apply0", 0), "k_apply<": ("residual", 1)}
+        # Level-0-only kernels: the band height adapts to the number of active pairs, so one solve launches the same
+        # symbol with several grid sizes -> per-launch mean over all of them (what bench.py's per-launch figure is).
+        # Stored-level kernels share a symbol across levels: label the grid with the largest total traffic (level 1).
+        names = {"k_sweep<vof::SweepFine": ("gs0", 0, True), "k_sweep<vof::SweepStored": ("gs", 1, False),
+                 "k_stream_apply0<0": ("apply0", 0, True), "k_apply<": ("residual", 1, False)}
         for sym, lst in by_sym.items():
-            for pat, (nm, first_level) in names.items():
-                if pat in sym:
-                    # only the largest grid of a class is labelled (forward / reverse sweeps of the deeper levels have
-                    # different grid sizes, so a rank is not a level there)
-                    for rank, (grid, n, rd, wr) in enumerate(sorted(lst, key=lambda t: -t[0])[:1]):
-                        k = f"{nm}_L{first_level + rank}_{size}x{size}x{frames}"
-                        if k in out:       # several template instantiations of one class: keep the busiest
-                            if out[k]["launches"] >= n:
-                                continue
-                        out[k] = {"hbm_bytes_per_launch": rd + wr, "fetch_x2_bytes": rd, "write_bytes": wr,
-                                  "launches": n, "kernel": sym, "grid": grid}
+            for pat, (nm, level, merge) in names.items():
+                if pat not in sym:
+                    continue
+                if merge:
+                    n = sum(t[1] for t in lst)
+                    rd = sum(t[1] * t[2] for t in lst) / n
+                    wr = sum(t[1] * t[3] for t in lst) / n
+                    grid = sorted(t[0] for t in lst)
+                else:
+                    grid, n, rd, wr = max(lst, key=lambda t: t[1] * (t[2] + t[3]))
+                k = f"{nm}_L{level}_{size}x{size}x{frames}"
+                if k in out and out[k]["launches"] * out[k]["hbm_bytes_per_launch"] >= n * (rd + wr):
+                    continue       # several template instantiations of one class: keep the busiest
+                out[k] = {"hbm_bytes_per_launch": rd + wr, "fetch_x2_bytes": rd, "write_bytes": wr,
+                          "launches": n, "kernel": sym, "grid": grid}
         json.dump(out, open(jpath, "w"), indent=1, sort_keys=True)
 
 
