@@ -314,3 +314,53 @@ def test_easy_regimes_never_touch_the_fallback(of):
     assert a["stats"]["iterations"].max() <= 8
     np.testing.assert_array_equal(a["v_x"], b["v_x"])
     np.testing.assert_array_equal(a["stats"]["iterations"], b["stats"]["iterations"])
+
+
+@pytest.mark.parametrize("shape", [(4, 1500), (1500, 4), (121, 123), (122, 129), (137, 241), (257, 120), (6, 259)])
+def test_strip_and_band_boundary_sizes(of, shape):
+    """Image sizes around the strip widths (120 / 128 columns) and band heights of the streaming kernels, and extremely
+    elongated images: the independent CPU residual of the GPU solution (oracle operator, OF.py:1150-1151) must meet the
+    tolerance, i.e. every kernel of the pipeline handled the ragged edges."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    n = max(shape)
+    base = orc.make_texture_stack(max(n, 16), 2, seed=shape[1])[:, :shape[0], :shape[1]]
+    movie = base + 0.01 * rng.random((2,) + shape)
+    res = of.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=200.0, rtol=1e-9, return_stats=True)
+    assert res["stats"]["converged"].all()
+    xi = np.stack([res["v_x"][0], res["v_y"][0], res["remodelling"][0]])[:, 1:-1, 1:-1]
+    b = orc.rhs_interior(movie[0], movie[1])
+    rr = np.linalg.norm(b - orc.apply_operator_interior(movie[0], xi, 1.0, 200.0)) / np.linalg.norm(b)
+    assert rr <= 2e-9
+    for k in ("v_x", "v_y", "remodelling", "speed"):        # mirror fix-up of the border (OF.py:1159-1166) is idempotent
+        f = res[k][0].copy()
+        of.apply_constant_boundary_condition(f)
+        np.testing.assert_array_equal(f, res[k][0])
+
+
+def test_input_forms_the_reference_accepts(of):
+    """OF.py:769 casts whatever it gets with astype(float): lists, Fortran order, strided views, small integer and
+    float32 dtypes all give the result of the equivalent float64 C-ordered array."""
+    base = np.round(orc.make_texture_stack(40, 3, seed=6) * 200.0)
+    ref = of.variational_optical_flow(base, speed_alpha=5e4, remodelling_alpha=1e3)
+    big = np.zeros((3, 80, 80)); big[:, ::2, ::2] = base
+    forms = {"list": base.tolist(), "fortran": np.asfortranarray(base), "strided": big[:, ::2, ::2],
+             "int16": base.astype(np.int16), "uint8": base.astype(np.uint8), "float32": base.astype(np.float32)}
+    for name, mv in forms.items():
+        res = of.variational_optical_flow(mv, speed_alpha=5e4, remodelling_alpha=1e3)
+        np.testing.assert_array_equal(res["v_x"], ref["v_x"], err_msg=name)
+        assert res["original_data"].dtype == np.float64 and res["v_x"].flags["C_CONTIGUOUS"]
+    with pytest.raises(ValueError):
+        of.variational_optical_flow(base[0])
+    with pytest.raises(ValueError):
+        of.variational_optical_flow(base[:1])
+
+
+def test_non_finite_input_is_reported_not_hung(of):
+    """A NaN pixel poisons its pair only: that pair is reported as not converged, the others are solved."""
+    movie = orc.make_texture_stack(48, 4, seed=12)
+    movie[1, 20, 20] = np.nan                      # frame 1 belongs to pairs 0 and 1
+    res = of.variational_optical_flow(movie, remodelling_alpha=1e4, max_iterations=50, return_stats=True)
+    st = res["stats"]
+    assert st["converged"].tolist() == [0, 0, 1]
+    assert np.isfinite(res["v_x"][2]).all() and st["relative_residual"][2] <= 1.5e-6
+    assert res["converged"] is True                # flag of the last pair, as in the reference
