@@ -229,7 +229,9 @@ def main():
     achieved = (bytes_per_launch / avg_s) / 1e9 if (bytes_per_launch and cnt) else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # the PMC passes were taken with all pairs of the stack in one batch; with chunked solves (multi-GPU overlap) a
+    # launch processes fewer pairs and the per-launch traffic figure does not apply
+    if os.path.exists(tpath) and B >= P:
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(f"{dom_name}_L{dom_level}_{n}x{n}x{T}", {}).get("hbm_bytes_per_launch")

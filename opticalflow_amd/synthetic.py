@@ -36,3 +36,18 @@ def texture_stack_torch(n, n_frames, seed, device, shift=(0.3, 0.6), first_frame
         A = (a[:, None] * torch.cos(p)).T @ torch.cos(q) - (a[:, None] * torch.sin(p)).T @ torch.sin(q)
         out[t] = torch.clamp(0.5 + scale * A, 0.0, 1.0)
     return out
+
+
+def texture_stack_numpy(n, n_frames, seed=0, shift=(0.3, 0.6), first_frame=0, n_modes=64):
+    """Host (numpy) version of ``texture_stack_torch``: same recipe, same parameters."""
+    f, g, a, phi = texture_parameters(n, seed, n_modes)
+    i = np.arange(n, dtype=np.float64)
+    scale = 0.45 * math.sqrt(n_modes) / (3.0 * float(a.sum()))
+    out = np.empty((n_frames, n, n))
+    for t in range(n_frames):
+        tt = first_frame + t
+        p = 2 * math.pi * f[:, None] * (i[None, :] - shift[0] * tt) / n + phi[:, None]
+        q = 2 * math.pi * g[:, None] * (i[None, :] - shift[1] * tt) / n
+        A = (a[:, None] * np.cos(p)).T @ np.cos(q) - (a[:, None] * np.sin(p)).T @ np.sin(q)
+        out[t] = np.clip(0.5 + scale * A, 0.0, 1.0)
+    return out

@@ -3,13 +3,13 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from opticalflow_amd import optical_flow as of
-from oracle import vof_oracle as orc     # input generator / CPU residual check only
+from opticalflow_amd.synthetic import texture_stack_numpy
 
 def run(n, regime, blur, T=3, **kw):
     if regime == "T": scale, a, b = 255.0, 1e4, 1e2
     elif regime == "W": scale, a, b = 255.0, 2e3, 1.0
     else: scale, a, b = 1.0, 1.0, 1e4
-    mv = orc.make_texture_stack(n, T, seed=1)
+    mv = texture_stack_numpy(n, T, seed=1)
     if scale > 1: mv = np.round(mv * scale)
     for method, extra in (("bicgstab", {}), ("auto", {}), ("gmres", {}), ("gmres", dict(gmres_restart=100))):
         t0 = time.time()

@@ -3,9 +3,9 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from opticalflow_amd import _native, optical_flow as of
-from oracle import vof_oracle as orc     # input generator only
+from opticalflow_amd.synthetic import texture_stack_numpy
 n, T = 1024, 256
-base = orc.make_texture_stack(n, 9, seed=1)
+base = texture_stack_numpy(n, 9, seed=1)
 movie = np.concatenate([base] * 29)[:T].copy()
 p = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4)
 def lap(label, t0):

@@ -3,9 +3,9 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from opticalflow_amd import optical_flow as of
-from oracle import vof_oracle as orc     # input generator only
+from opticalflow_amd.synthetic import texture_stack_numpy
 for n in (258, 514, 1026):
-    mv = np.round(orc.make_texture_stack(n, 3, seed=1) * 255.0)
+    mv = np.round(texture_stack_numpy(n, 3, seed=1) * 255.0)
     for regime, a, b in (("T", 1e4, 1e2), ("W", 2e3, 1.0)):
         for blur in (None, 2.0):
             for quirks in (True, False):

@@ -4,10 +4,10 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from opticalflow_amd import optical_flow as of
-from oracle import vof_oracle as orc   # input generator only
+from opticalflow_amd.synthetic import texture_stack_numpy
 
 n, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (512, 17)
-movie = orc.make_texture_stack(n, T, seed=1)
+movie = texture_stack_numpy(n, T, seed=1)
 sa, ra = np.array([0.5, 1.0, 2.0]), np.array([3e3, 1e4, 3e4])
 of.vary_regularisation(movie[:3], sa[:1], ra[:1])          # warm-up
 t0 = time.time(); r = of.vary_regularisation(movie, sa, ra, return_stats=True); t_native = time.time() - t0
