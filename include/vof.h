@@ -54,7 +54,7 @@ typedef struct vof_params {
                                   same stopping rule; `iterations` counts the Krylov steps of both phases */
     int32_t gmres_restart;     /* restart length (default 100, at most 128); the basis takes (restart + 1) float64 vectors per pair in
                                   flight and is capped at half of the free device memory when the fallback first runs */
-    int32_t fallback_after;    /* BiCGStab iterations before the fallback (default 8) */
+    int32_t fallback_after;    /* BiCGStab iterations before the fallback (default 25) */
     int32_t reserved;
 } vof_params;
 

@@ -56,6 +56,8 @@ struct vof_ctx {
     double* kz = nullptr;
     double* b32 = nullptr;  // V-typed copy of the V-cycle right-hand side (p or s) when vfloat
     bool vfloat = false;    // V-cycle vectors stored as float32 (arithmetic stays FP64)
+    const PairParam* pp = nullptr;   // per-pair (alpha, beta, frame) overrides of the current batch ("virtual pairs") or nullptr
+    PairParam* pp_buf = nullptr;     // device storage for them (B entries, lazy)
     double* partials = nullptr;
     int nblk = 0;
     PairScalars* sc = nullptr;
@@ -204,7 +206,7 @@ void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np
     if (l == 0 && c->L.size() > 1) {
         Prof p(c, VOF_K_GS0, 0, 20.0 * lv.npts);
         k_gs0<<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->prm.speed_alpha,
-                                          c->prm.remodelling_alpha, c->prm.reference_quirks, x, b, colour, active);
+                                          c->prm.remodelling_alpha, c->prm.reference_quirks, x, b, colour, active, c->pp);
     } else {
         Prof p(c, VOF_K_GS, l, (81.0 * cb + 72.0) / 4.0 * lv.npts);
         if (c->hierarchy_float && l > 0)
@@ -255,22 +257,22 @@ void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np,
         if (mode)
             k_stream_apply0<1, XT, BT, YT><<<ag.grid, AP_THREADS, 0, c->stream>>>(
                 c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, ag.TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
-                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active);
+                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active, c->pp);
         else
             k_stream_apply0<0, XT, BT, YT><<<ag.grid, AP_THREADS, 0, c->stream>>>(
                 c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, ag.TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
-                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active);
+                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active, c->pp);
         return;
     }
     dim3 g = grid2d(lv.ni, lv.nj, np);
     if (mode)
         k_apply0<1, XT, BT, YT><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
                                                             c->prm.speed_alpha, c->prm.remodelling_alpha,
-                                                            c->prm.reference_quirks, x, b, y, active);
+                                                            c->prm.reference_quirks, x, b, y, active, c->pp);
     else
         k_apply0<0, XT, BT, YT><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
                                                             c->prm.speed_alpha, c->prm.remodelling_alpha,
-                                                            c->prm.reference_quirks, x, b, y, active);
+                                                            c->prm.reference_quirks, x, b, y, active, c->pp);
 }
 
 template <typename VT>
@@ -330,7 +332,7 @@ void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, VT* bc, int np, co
     Prof p(c, VOF_K_APPLY0, 0, (8.0 + 6.0 * sizeof(VT)) * f.npts + 3.0 * sizeof(VT) * k.npts);
     k_stream_resrestrict0<VT, VT, VT><<<g, AP_THREADS, 0, c->stream>>>(
         c->frames, frame_stride(c), c->Nj, f.ni, f.nj, TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
-        c->prm.reference_quirks, x, b, bc, k.ni, k.nj, active);
+        c->prm.reference_quirks, x, b, bc, k.ni, k.nj, active, c->pp);
 }
 
 template <typename VT>
@@ -367,6 +369,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         SweepFine pol;
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
         pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
+        pol.pp = c->pp;
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double) +
                      (ecoarse ? (size_t)(3 * 3 * (W / 2 + 2)) * sizeof(VT) : 0);
         if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
@@ -478,19 +481,19 @@ int build_hierarchy(vof_ctx* c, int np) {
             if (c->hierarchy_float)
                 k_galerkin<double, float, true><<<g, blk2d, 0, c->stream>>>(
                     c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
-                    nullptr, f.ni, f.nj, (float*)k.C, k.ni, k.nj);
+                    nullptr, f.ni, f.nj, (float*)k.C, k.ni, k.nj, c->pp);
             else
                 k_galerkin<double, double, true><<<g, blk2d, 0, c->stream>>>(
                     c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
-                    nullptr, f.ni, f.nj, (double*)k.C, k.ni, k.nj);
+                    nullptr, f.ni, f.nj, (double*)k.C, k.ni, k.nj, c->pp);
         } else {
             Prof p(c, VOF_K_GALERKIN, l);
             if (c->hierarchy_float)
                 k_galerkin<float, float, false><<<g, blk2d, 0, c->stream>>>(
-                    nullptr, 0, 0, 0.0, 0.0, 0, (const float*)f.C, f.ni, f.nj, (float*)k.C, k.ni, k.nj);
+                    nullptr, 0, 0, 0.0, 0.0, 0, (const float*)f.C, f.ni, f.nj, (float*)k.C, k.ni, k.nj, nullptr);
             else
                 k_galerkin<double, double, false><<<g, blk2d, 0, c->stream>>>(
-                    nullptr, 0, 0, 0.0, 0.0, 0, (const double*)f.C, f.ni, f.nj, (double*)k.C, k.ni, k.nj);
+                    nullptr, 0, 0, 0.0, 0.0, 0, (const double*)f.C, f.ni, f.nj, (double*)k.C, k.ni, k.nj, nullptr);
         }
     }
     return 0;
@@ -502,11 +505,14 @@ int build_hierarchy(vof_ctx* c, int np) {
 namespace vof {
 __global__ __launch_bounds__(NT) void k_store_fine_stencil(const double* __restrict__ frames, size_t frame_stride,
                                                            int Nj, double alpha, double beta, int quirks, int ni,
-                                                           int nj, double* __restrict__ C) {
+                                                           int nj, double* __restrict__ C,
+                                                           const PairParam* __restrict__ pp) {
     int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q;
-    PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
+    PixCoef k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, p, q, quirks);
     const CLay L(ni, nj);
     double* out = C + (size_t)pair * 81 * L.plane + L.idx(p, q);
     (void)idx;
@@ -537,7 +543,7 @@ int setup_batch(vof_ctx* c, const double* frames_dev, int np) {
         Prof p(c, VOF_K_GALERKIN0, 0);
         k_store_fine_stencil<<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(
             c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha,
-            c->prm.reference_quirks, f.ni, f.nj, (double*)f.C);
+            c->prm.reference_quirks, f.ni, f.nj, (double*)f.C, c->pp);
         c->hierarchy_float = false;
     } else {
         build_hierarchy(c, np);
@@ -679,7 +685,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     // right-hand side and its norm
     {
         Prof p(c, VOF_K_RHS, 0);
-        k_rhs<<<grid2d(f.ni, f.nj, np), blk2d, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb);
+        k_rhs<<<grid2d(f.ni, f.nj, np), blk2d, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb, c->pp);
     }
     { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kb, c->kb, nullptr, nullptr, len, c->partials, nullptr); }
     { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_BNORM><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
@@ -746,7 +752,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
     { Prof p(c, VOF_K_FUNCTIONALS, 0);
       k_functionals<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, P.speed_alpha,
-                                                  P.remodelling_alpha, P.reference_quirks, c->kx, c->partials);
+                                                  P.remodelling_alpha, P.reference_quirks, c->kx, c->partials, c->pp);
       k_sum3<<<np, 64, 0, s>>>(c->partials, c->nblk, c->func3); }
     { Prof p(c, VOF_K_FINALIZE, 0);
       k_finalize<<<grid2d(c->Ni, c->Nj, np), blk2d, 0, s>>>(c->kx, f.ni, f.nj, P.delta_x / P.delta_t, vx, vy, gm, speed); }
@@ -814,7 +820,7 @@ void vof_default_params(vof_params* p) {
     p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)
     p->krylov_method = 2;          // BiCGStab (the reference's 'bcgs'); stragglers are finished by restarted GMRES
     p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
-    p->fallback_after = 8;         // BiCGStab iterations before the fallback (the benchmark workloads need 3-5)
+    p->fallback_after = 25;        // BiCGStab iterations before the fallback (the benchmark regimes need 3-17)
 }
 
 const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -1190,12 +1196,64 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
     }
     if (blur_weights)
         if (int rc = vof_blur_stack_dev(c, dmovie, dmovie, n_frames, blur_weights, blur_radius)) return fail(rc);
-    std::vector<vof_pair_stats> st((size_t)P);
-    for (int i = 0; i < n_sa; ++i)
-        for (int j = 0; j < n_ra; ++j) {
+    auto summarise = [&](vof_variation_stats& o, const vof_pair_stats* st, const Moments& ms, const Moments& mr) {
+        memset(&o, 0, sizeof o);
+        o.speed_mean = ms.mean; o.speed_variance = ms.m2 / ms.n;
+        o.remodelling_mean = mr.mean; o.remodelling_variance = mr.m2 / mr.n;
+        o.converged_all = 1;
+        for (int k = 0; k < P; ++k) {
+            o.L1_functional += st[k].L1_functional;
+            o.speed_functional += st[k].speed_functional;
+            o.remodelling_functional += st[k].remodelling_functional;
+            o.max_relative_residual = std::max(o.max_relative_residual, st[k].relative_residual);
+            o.max_iterations_used = std::max(o.max_iterations_used, st[k].iterations);
+            o.converged_all &= st[k].converged;
+        }
+        o.converged_last = st[P - 1].converged;
+    };
+    const int n_comb = n_sa * n_ra;
+    for (int t = 0; t < n_comb; ++t) {   // validate every combination before any work
+        vof_params q = *base;
+        q.speed_alpha = speed_alphas[t / n_ra];
+        q.remodelling_alpha = remodelling_alphas[t % n_ra];
+        if (int rc = check_params(c, &q)) return fail(rc);
+    }
+    if (int rc = check_params(c, base)) return fail(rc);
+    if (P <= c->B) {
+        // Short movies leave the chip idle (16 pairs of 512^2 fill a third of it): solve G combinations at once as
+        // G * P "virtual pairs" of one batch - pair v = (combination v / P, frame pair v % P) reads its own
+        // (alpha, beta) and frame index from the PairParam table.
+        const int G = std::max(1, c->B / P);
+        if (!c->pp_buf) { if (int rc = dev_alloc(c, &c->pp_buf, (size_t)c->B)) return fail(rc); }
+        std::vector<PairParam> hp((size_t)G * P);
+        std::vector<vof_pair_stats> st((size_t)G * P);
+        for (int t0 = 0; t0 < n_comb; t0 += G) {
+            const int g = std::min(G, n_comb - t0), np = g * P;
+            for (int u = 0; u < g; ++u)
+                for (int k = 0; k < P; ++k)
+                    hp[(size_t)u * P + k] = PairParam{speed_alphas[(t0 + u) / n_ra], remodelling_alphas[(t0 + u) % n_ra], k, 0};
+            HIPCHK(hipStreamSynchronize(c->stream));   // hp is re-used: the previous upload must have completed
+            if (hipMemcpyAsync(c->pp_buf, hp.data(), (size_t)np * sizeof(PairParam), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                c->err = "H2D copy failed";
+                return fail(-2);
+            }
+            c->pp = c->pp_buf;
+            int rc = solve_batch(c, dmovie, np, c->st_out[0], c->st_out[1], c->st_out[2], c->st_out[3], st.data());
+            c->pp = nullptr;
+            if (rc) return fail(rc);
+            for (int u = 0; u < g; ++u) {
+                Moments ms, mr;
+                if (int rc2 = chunk_moments(c, c->st_out[3] + (size_t)u * P * fs, (size_t)P * fs, &ms)) return fail(rc2);
+                if (int rc2 = chunk_moments(c, c->st_out[2] + (size_t)u * P * fs, (size_t)P * fs, &mr)) return fail(rc2);
+                summarise(out[t0 + u], st.data() + (size_t)u * P, ms, mr);
+            }
+        }
+    } else {
+        std::vector<vof_pair_stats> st((size_t)P);
+        for (int t = 0; t < n_comb; ++t) {
             vof_params q = *base;
-            q.speed_alpha = speed_alphas[i];
-            q.remodelling_alpha = remodelling_alphas[j];
+            q.speed_alpha = speed_alphas[t / n_ra];
+            q.remodelling_alpha = remodelling_alphas[t % n_ra];
             if (int rc = check_params(c, &q)) return fail(rc);
             Moments ms, mr;
             for (int k0 = 0; k0 < P; k0 += c->B) {
@@ -1205,21 +1263,9 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
                 if (int rc = chunk_moments(c, c->st_out[3], (size_t)np * fs, &ms)) return fail(rc);
                 if (int rc = chunk_moments(c, c->st_out[2], (size_t)np * fs, &mr)) return fail(rc);
             }
-            vof_variation_stats& o = out[(size_t)i * n_ra + j];
-            memset(&o, 0, sizeof o);
-            o.speed_mean = ms.mean; o.speed_variance = ms.m2 / ms.n;
-            o.remodelling_mean = mr.mean; o.remodelling_variance = mr.m2 / mr.n;
-            o.converged_all = 1;
-            for (int k = 0; k < P; ++k) {
-                o.L1_functional += st[k].L1_functional;
-                o.speed_functional += st[k].speed_functional;
-                o.remodelling_functional += st[k].remodelling_functional;
-                o.max_relative_residual = std::max(o.max_relative_residual, st[k].relative_residual);
-                o.max_iterations_used = std::max(o.max_iterations_used, st[k].iterations);
-                o.converged_all &= st[k].converged;
-            }
-            o.converged_last = st[P - 1].converged;
+            summarise(out[t], st.data(), ms, mr);
         }
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return fail(0);
 }
@@ -1237,7 +1283,7 @@ int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof
     Level& f = c->L[0];
     {
         Prof pr(c, VOF_K_RHS, 0);
-        k_rhs<<<grid2d(f.ni, f.nj, n_pairs), blk2d, 0, c->stream>>>(movie, frame_stride(c), c->Nj, f.ni, f.nj, c->kb);
+        k_rhs<<<grid2d(f.ni, f.nj, n_pairs), blk2d, 0, c->stream>>>(movie, frame_stride(c), c->Nj, f.ni, f.nj, c->kb, nullptr);
     }
     HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)n_pairs * 3 * f.npts * sizeof(double), c->stream));
     if (c->vfloat) {
@@ -1373,7 +1419,7 @@ static int dbg_down(vof_ctx* c, double* host, const void* src_v, size_t n) {
 
 int vof_debug_rhs(vof_ctx* c, double* b_host) {
     DBG_LEVEL(0)
-    k_rhs<<<grid2d(lv.ni, lv.nj, c->npairs), blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->kb);
+    k_rhs<<<grid2d(lv.ni, lv.nj, c->npairs), blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->kb, nullptr);
     HIPCHK(hipMemcpyAsync(b_host, c->kb, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

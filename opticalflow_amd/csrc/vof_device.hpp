@@ -30,6 +30,15 @@ struct PairScalars {
     int halfstep;     // 1: converged at the half step, x += alpha y still pending; 2: done
 };
 
+// Per-pair overrides for "virtual pairs" (vary_regularisation batches several (speed_alpha, remodelling_alpha)
+// combinations of the same movie into one launch): regularisation parameters and the index of the pair's first frame.
+// Kernels take a `const PairParam* pp`; nullptr (the normal case) = kernel arguments / frame index = pair index.
+struct PairParam {
+    double alpha, beta;
+    int frame;
+    int pad;
+};
+
 __device__ __forceinline__ int fold(int t, int n) { return t < 0 ? 1 : (t >= n ? n - 2 : t); }
 
 // weight of fine point f in the prolongation column of coarse point c (1-D), nc = #coarse points.
@@ -181,10 +190,10 @@ __device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double 
 // k_rhs: b = (-P Dxt, -P Dyt, -Dt) on the interior (OF.py:889,938,962).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_rhs(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
-                                            int nj, double* __restrict__ b) {
+                                            int nj, double* __restrict__ b, const PairParam* __restrict__ pp) {
     int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (p >= ni || q >= nj) return;
-    const double* I = frames + (size_t)pair * frame_stride + (size_t)(p + 1) * Nj + (q + 1);
+    const double* I = frames + (size_t)(pp ? pp[pair].frame : pair) * frame_stride + (size_t)(p + 1) * Nj + (q + 1);
     const double* J = I + frame_stride;
     double P = I[0];
     double dxt = (J[Nj] - J[-Nj] - I[Nj] + I[-Nj]) / 2;  // OF.py:815-816
@@ -205,12 +214,15 @@ template <int MODE, typename XT, typename BT, typename YT>
 __global__ __launch_bounds__(NT) void k_apply0(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
                                                int nj, double alpha, double beta, int quirks,
                                                const XT* __restrict__ x, const BT* __restrict__ b,
-                                               YT* __restrict__ y, const int* __restrict__ active) {
+                                               YT* __restrict__ y, const int* __restrict__ active,
+                                               const PairParam* __restrict__ pp) {
     int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (active && !active[pair]) return;
     if (p >= ni || q >= nj) return;
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
-    PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
+    PixCoef k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, p, q, quirks);
     Nbr n;
     load_nbr(x + off, npts, ni, nj, p, q, n);
     double y0, y1, y2;
@@ -237,14 +249,16 @@ __global__ __launch_bounds__(NT) void k_apply0(const double* __restrict__ frames
 __global__ __launch_bounds__(NT) void k_gs0(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
                                             int nj, double alpha, double beta, int quirks, double* __restrict__ x,
                                             const double* __restrict__ b, int colour,
-                                            const int* __restrict__ active) {
+                                            const int* __restrict__ active, const PairParam* __restrict__ pp) {
     int pair = blockIdx.z;
     if (active && !active[pair]) return;
     int q = 2 * (blockIdx.x * BX + threadIdx.x) + (colour & 1);
     int p = 2 * (blockIdx.y * BY + threadIdx.y) + (colour >> 1);
     if (p >= ni || q >= nj) return;
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
-    PixCoef k = pix_coef(frames + (size_t)pair * frame_stride, Nj, p, q, quirks);
+    PixCoef k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, p, q, quirks);
     Nbr n;
     load_nbr(x + off, npts, ni, nj, p, q, n);
     double y0, y1, y2;
@@ -429,10 +443,13 @@ template <typename CTF, typename CTC, bool LEVEL0>
 __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ frames, size_t frame_stride, int Nj,
                                                  double alpha, double beta, int quirks,
                                                  const CTF* __restrict__ Cf, int nfi, int nfj,
-                                                 CTC* __restrict__ Cc, int nci, int ncj) {
+                                                 CTC* __restrict__ Cc, int nci, int ncj,
+                                                 const PairParam* __restrict__ pp) {
     int cq = blockIdx.x * BX + threadIdx.x, cp = blockIdx.y * BY + threadIdx.y;
     int pair = blockIdx.z;
     if (cp >= nci || cq >= ncj) return;
+    int fidx = pair;
+    if (LEVEL0 && pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     const CLay Lf(nfi, nfj), Lc(nci, ncj);
     const size_t nf = Lf.plane, nc = Lc.plane;
     double acc[9][9];
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
             if (fq < 0 || fq >= nfj) continue;
             const double wf = wfi * pweight(fq, cq, ncj);
             PixCoef k;
-            if (LEVEL0) k = pix_coef(frames + (size_t)pair * frame_stride, Nj, fp, fq, quirks);
+            if (LEVEL0) k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, fp, fq, quirks);
             const CTF* fb = LEVEL0 ? nullptr : Cf + (size_t)pair * 81 * nf + Lf.idx(fp, fq);
 #pragma unroll
             for (int oi = -1; oi <= 1; ++oi) {
@@ -888,13 +905,16 @@ __global__ __launch_bounds__(NT) void k_finalize(const double* __restrict__ x, i
 // Functionals of OF.py:1167-1183 on the BC-fixed fields (velocities in pixels/frame).
 __global__ __launch_bounds__(RBLK) void k_functionals(const double* __restrict__ frames, size_t frame_stride, int Nj,
                                                       int ni, int nj, double alpha, double beta, int quirks,
-                                                      const double* __restrict__ x, double* __restrict__ partials) {
+                                                      const double* __restrict__ x, double* __restrict__ partials,
+                                                      const PairParam* __restrict__ pp) {
     int pair = blockIdx.y;
     size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     const double* xu = x + off;
     const double* xw = xu + npts;
     const double* xg = xw + npts;
-    const double* I = frames + (size_t)pair * frame_stride;
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
+    const double* I = frames + (size_t)fidx * frame_stride;
     const double* J = I + frame_stride;
     double sL = 0, sS = 0, sR = 0;
     for (size_t t = (size_t)blockIdx.x * RBLK + threadIdx.x; t < npts; t += (size_t)gridDim.x * RBLK) {
@@ -1222,6 +1242,7 @@ struct SweepFine {
     int Nj;
     double alpha, beta;
     int quirks;
+    const PairParam* pp;   // per-pair overrides (virtual pairs) or nullptr
     static constexpr bool kHasImage = true;
     static constexpr int kPrefetch = 0;   // no per-point coefficient planes
     typedef float coef_t;
@@ -1391,7 +1412,11 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     const size_t ncpts = (size_t)nci * ncj;
     const VT* ec = (ecoarse && !G::HALO_WAVE) ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
     const double* img = nullptr;
-    if (Pol::kHasImage) img = pol.frames + (size_t)pair * pol.frame_stride;
+    if constexpr (Pol::kHasImage) {
+        int fidx = pair;
+        if (pol.pp) { pol.alpha = pol.pp[pair].alpha; pol.beta = pol.pp[pair].beta; fidx = pol.pp[pair].frame; }
+        img = pol.frames + (size_t)fidx * pol.frame_stride;
+    }
     const CLay L(ni, nj);
 
     // ---- stage of this lane.  Waves 0-3: colour = wave.  GeoB: wave 4 recomputes the six halo points.
@@ -1676,12 +1701,14 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
     const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj, int TI, double alpha, double beta,
     int quirks, const XT* __restrict__ x, const BT* __restrict__ b, YT* __restrict__ y,
     const double* __restrict__ dotvec, int want_yy, double* __restrict__ partials, int nblk,
-    const int* __restrict__ active) {
+    const int* __restrict__ active, const PairParam* __restrict__ pp) {
     __shared__ XT xs[AP_RING * 3 * AP_W];
     __shared__ double im[AP_RING * AP_W];
     __shared__ double red[2][AP_THREADS / 64];
     const int pair = blockIdx.z;
     if (active && !active[pair]) return;
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     const int tid = threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);   // which of the two rows of a step
     const int col = tid & 127;
@@ -1690,7 +1717,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
     const bool col_ok = q < nj;
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     const XT* xp = x + off;
-    const double* img = frames + (size_t)pair * frame_stride;
+    const double* img = frames + (size_t)fidx * frame_stride;
     // x ring local column of q is col + 1 (local 0 <-> q0 - 1); ghost columns fold onto their mirror
     const bool oL = q - 1 < 0, oR = q + 1 >= nj;
     const int cC = col + 1, cL = oL ? col + 2 : col, cR = oR ? col : col + 2;
@@ -1819,12 +1846,14 @@ template <typename XT, typename BT, typename CT2>
 __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
     const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj, int TI, double alpha, double beta,
     int quirks, const XT* __restrict__ x, const BT* __restrict__ b, CT2* __restrict__ bc, int nci, int ncj,
-    const int* __restrict__ active) {
+    const int* __restrict__ active, const PairParam* __restrict__ pp) {
     __shared__ XT xs[AP_RING * 3 * AP_W];
     __shared__ double im[AP_RING * AP_W];
     __shared__ double rs[AP_RING * 3 * 128];     // residual ring [row][field][fine column of the strip]
     const int pair = blockIdx.z;
     if (active && !active[pair]) return;
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     const int tid = threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int col = tid & 127;
@@ -1834,7 +1863,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
     const bool col_ok = q >= 0 && q < nj;
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     const XT* xp = x + off;
-    const double* img = frames + (size_t)pair * frame_stride;
+    const double* img = frames + (size_t)fidx * frame_stride;
     const bool oL = q - 1 < 0, oR = q + 1 >= nj;
     const int cC = col + 1, cL = oL ? col + 2 : col, cR = oR ? col : col + 2;
     // restriction phase: thread <-> (field, coarse column of the strip)

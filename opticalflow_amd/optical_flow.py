@@ -88,6 +88,10 @@ def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap
 def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                    use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
                    multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None):
+    # krylov_method may be a tuple ("auto", fallback_after): BiCGStab iterations before GMRES takes over
+    fallback_after = None
+    if isinstance(krylov_method, (tuple, list)):
+        krylov_method, fallback_after = krylov_method[0], int(krylov_method[1])
     """vof_params from the keyword arguments of ``variational_optical_flow``."""
     if rtol is None:
         rtol = 1e-11 if use_direct_solver else 1e-6
@@ -111,6 +115,8 @@ def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x
     params.krylov_method = {"bicgstab": 0, "gmres": 1, "auto": 2}[krylov_method]
     if gmres_restart is not None:
         params.gmres_restart = int(gmres_restart)
+    if fallback_after is not None:
+        params.fallback_after = fallback_after
     return params
 
 
@@ -165,7 +171,7 @@ def variational_optical_flow(movie,
         ``w_cycle_level`` (-1: V-cycle; ``l``: level ``l`` visits level ``l+1`` twice per cycle),
         ``krylov_method`` ("bicgstab": the reference's KSP type, OF.py:1081; "gmres": restarted GMRES with the same
         preconditioner and stopping rule; "auto" (default): BiCGStab, and GMRES(``gmres_restart``, default 100) for the
-        pairs that have not converged after 8 iterations - the grad-div dominated regimes),
+        pairs that have not converged after 25 iterations - the grad-div dominated regimes),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals), ``output`` ("numpy": host arrays as in the reference; "torch": ``movie`` may be a
         torch tensor already on the device and every array of the result stays on the device as a float64 torch
@@ -305,7 +311,9 @@ def vary_regularisation(movie,
                             kw["reference_quirks"], kw["coarse_precision"], kw["vcycle_precision"],
                             kw["multigrid_sweeps"], kw["w_cycle_level"], kw["krylov_method"], kw["gmres_restart"])
     taps = None if kw["smoothing_sigma"] is None else gaussian_taps(kw["smoothing_sigma"])
-    pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, T - 1, kw["device"])
+    # short movies: several combinations share one batch as "virtual pairs" (see vof_vary_regularisation_host)
+    n_comb = max(1, len(speed_alpha_values) * len(remodelling_alpha_values))
+    pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, (T - 1) * n_comb, kw["device"])
     with _native.Solver(N_i, N_j, pairs, device=kw["device"]) as solver:
         rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,
                                               remodelling_alpha_values, taps)

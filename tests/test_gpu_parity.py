@@ -287,8 +287,8 @@ def test_gmres_reaches_the_reference_solution(of, name):
 
 def test_gmres_fallback_finishes_what_bicgstab_starts(of):
     """8-bit data without blur, alpha / I^2 ~ 0.15 (the grad-div dominated regime): BiCGStab needs
-    > 100 iterations at 258^2; the default hands the pairs to GMRES after 8 iterations, which converges in about a
-    quarter of the multigrid cycles.  Both satisfy the reference's stopping rule (checked on the CPU) and agree to
+    > 100 iterations at 258^2; the default hands the pairs to GMRES after 25 iterations, which then needs far
+    fewer multigrid cycles.  Both satisfy the reference's stopping rule (checked on the CPU) and agree to
     the accuracy that rule implies."""
     movie = np.round(orc.make_texture_stack(258, 3, seed=1) * 255.0)
     kw = dict(speed_alpha=1e4, remodelling_alpha=1e2, return_stats=True)
@@ -296,9 +296,9 @@ def test_gmres_fallback_finishes_what_bicgstab_starts(of):
     bicg = of.variational_optical_flow(movie, krylov_method="bicgstab", **kw)
     for r in (auto, bicg):
         assert r["stats"]["converged"].all() and r["stats"]["relative_residual"].max() <= 1.5e-6
-    cycles_auto = 2 * 8 + (auto["stats"]["iterations"] - 8)      # BiCGStab: two cycles per iteration, GMRES: one
+    cycles_auto = 2 * 25 + (auto["stats"]["iterations"] - 25)    # BiCGStab: two cycles per iteration, GMRES: one
     assert (cycles_auto < 2 * bicg["stats"]["iterations"]).all()
-    assert auto["stats"]["iterations"].max() <= 120
+    assert auto["stats"]["iterations"].max() <= 140
     xi = np.stack([auto["v_x"][0], auto["v_y"][0], auto["remodelling"][0]])[:, 1:-1, 1:-1]
     b = orc.rhs_interior(movie[0], movie[1])
     rr = np.linalg.norm(b - orc.apply_operator_interior(movie[0], xi, 1e4, 1e2)) / np.linalg.norm(b)
@@ -311,7 +311,7 @@ def test_easy_regimes_never_touch_the_fallback(of):
     movie = orc.make_texture_stack(96, 4, seed=2)
     a = of.variational_optical_flow(movie, remodelling_alpha=1e4, return_stats=True)
     b = of.variational_optical_flow(movie, remodelling_alpha=1e4, krylov_method="bicgstab", return_stats=True)
-    assert a["stats"]["iterations"].max() <= 8
+    assert a["stats"]["iterations"].max() <= 8           # far below the switch (25)
     np.testing.assert_array_equal(a["v_x"], b["v_x"])
     np.testing.assert_array_equal(a["stats"]["iterations"], b["stats"]["iterations"])
 
