@@ -45,12 +45,10 @@ def algorithmic_bytes_per_pixel(kernel, coarse_bytes):
 
 
 def largest_batch(n_pairs, per_pair_bytes, budget_bytes):
+    """Pairs in flight: all of them if they fit the memory budget, else the fewest equal-sized batches that do."""
     cap = max(1, int(budget_bytes // per_pair_bytes))
-    best = 1
-    for d in range(1, n_pairs + 1):
-        if n_pairs % d == 0 and d <= cap:
-            best = d
-    return best
+    n_batches = -(-n_pairs // cap)
+    return max(1, -(-n_pairs // n_batches))
 
 
 def cpu_baseline(size, seed):
