@@ -678,6 +678,9 @@ int gmres_phase(vof_ctx* c, int np) {
 int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double* vy, double* gm, double* speed,
                 vof_pair_stats* stats) {
     const vof_params& P = c->prm;
+    // storage type of the cycle vectors for this batch (an earlier batch may have switched to float64: "auto"
+    // precision after 8 iterations, GMRES fallback)
+    c->vfloat = P.vcycle_precision >= 1 && c->fused && c->L.size() > 1;
     if (int rc = setup_batch(c, frames_dev, np)) return rc;
     Level& f = c->L[0];
     const size_t len = 3 * f.npts;
