@@ -542,59 +542,57 @@ __global__ void k_coarse_build(const CT* __restrict__ C, int ni, int nj, double*
     }
 }
 
-__global__ void k_coarse_invert(double* __restrict__ W, int nd, double* __restrict__ invT) {
+constexpr int COARSE_ND_MAX = 3 * 9 * 9;   // 3 fields on at most 9 x 9 points (COARSEST_MAX in vof.hip)
+
+// 1024 threads = 16 waves: wave 0 finds the pivot, the scaled pivot row and the multiplier column are staged in LDS,
+// then wave w eliminates rows w, w + 16, ... (64 columns per step, coalesced; rows with a zero multiplier are skipped -
+// the matrix is banded, so most are in the early steps).
+__global__ __launch_bounds__(1024) void k_coarse_invert(double* __restrict__ W, int nd, double* __restrict__ invT) {
     int pair = blockIdx.x;
     double* Wp = W + (size_t)pair * nd * 2 * nd;
     const int ld = 2 * nd;
-    __shared__ double s_val[1024];
-    __shared__ int s_idx[1024];
+    __shared__ double prow[2 * COARSE_ND_MAX];
+    __shared__ double pcol[COARSE_ND_MAX];
     __shared__ int s_piv;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, nty = blockDim.x >> 6;
     for (int k = 0; k < nd; ++k) {
-        // pivot search in column k, rows >= k
-        double best = -1.0;
-        int bi = k;
-        for (int i = k + threadIdx.x; i < nd; i += blockDim.x) {
-            double v = fabs(Wp[(size_t)i * ld + k]);
-            if (v > best) { best = v; bi = i; }
-        }
-        s_val[threadIdx.x] = best;
-        s_idx[threadIdx.x] = bi;
-        __syncthreads();
-        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-            if (threadIdx.x < s) {
-                double v2 = s_val[threadIdx.x + s];
-                int i2 = s_idx[threadIdx.x + s];
-                if (v2 > s_val[threadIdx.x] || (v2 == s_val[threadIdx.x] && i2 < s_idx[threadIdx.x])) {
-                    s_val[threadIdx.x] = v2;
-                    s_idx[threadIdx.x] = i2;
-                }
+        if (ty == 0) {   // pivot search in column k, rows >= k (largest magnitude, lowest index on ties)
+            double best = -1.0;
+            int bi = k;
+            for (int i = k + tx; i < nd; i += 64) {
+                double v = fabs(Wp[(size_t)i * ld + k]);
+                if (v > best) { best = v; bi = i; }
             }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) s_piv = s_idx[0];
-        __syncthreads();
-        int piv = s_piv;
-        if (piv != k) {
-            for (int j = k + threadIdx.x; j < ld; j += blockDim.x) {
-                double t1 = Wp[(size_t)k * ld + j], t2 = Wp[(size_t)piv * ld + j];
-                Wp[(size_t)k * ld + j] = t2;
-                Wp[(size_t)piv * ld + j] = t1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                double v2 = __shfl_down(best, o, 64);
+                int i2 = __shfl_down(bi, o, 64);
+                if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
             }
+            if (tx == 0) s_piv = bi;
         }
         __syncthreads();
-        double pinv = 1.0 / Wp[(size_t)k * ld + k];
-        // eliminate column k from every other row over columns k+1 .. 2nd-1 (row swaps permute the
-        // identity half, so no column range of it can be skipped); column k itself is never written,
-        // so the multipliers stay valid during the step.
-        int ncol = ld - k - 1;
-        for (int t = threadIdx.x; t < nd * ncol; t += blockDim.x) {
-            int i = t / ncol, j = k + 1 + t % ncol;
-            if (i == k) continue;
-            double m = Wp[(size_t)i * ld + k] * pinv;
-            Wp[(size_t)i * ld + j] -= m * Wp[(size_t)k * ld + j];
+        const int piv = s_piv;
+        const double pinv = 1.0 / Wp[(size_t)piv * ld + k];
+        __syncthreads();   // every thread has read the pivot element before the swap overwrites it
+        // scaled pivot row -> LDS; row piv <- old row k (the swap; columns <= k are never read again)
+        for (int j = threadIdx.x; j < ld; j += blockDim.x) {
+            double a = Wp[(size_t)piv * ld + j], b = Wp[(size_t)k * ld + j];
+            prow[j] = a * pinv;
+            if (piv != k) Wp[(size_t)piv * ld + j] = b;
         }
         __syncthreads();
-        for (int j = k + 1 + threadIdx.x; j < ld; j += blockDim.x) Wp[(size_t)k * ld + j] *= pinv;
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) pcol[i] = (i == k) ? 0.0 : Wp[(size_t)i * ld + k];
+        __syncthreads();
+        // eliminate column k from every other row over columns k+1 .. 2nd-1 (row swaps permute the identity half, so
+        // no column range of it can be skipped); column k itself is never written.
+        for (int i = ty; i < nd; i += nty) {
+            const double m = pcol[i];
+            if (m == 0.0) continue;
+            double* row = Wp + (size_t)i * ld;
+            for (int j = k + 1 + tx; j < ld; j += 64) row[j] -= m * prow[j];
+        }
+        for (int j = k + 1 + threadIdx.x; j < ld; j += blockDim.x) Wp[(size_t)k * ld + j] = prow[j];
         __syncthreads();
     }
     double* out = invT + (size_t)pair * nd * nd;
