@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """The reference's only enabled experiment (analysis/analyse_variational_optical_flow.py:26-66,
 ``simple_test_with_data_on_boundary``) run against the MI355X-native drop-in module: two 50x50 frames of a
-translating Gaussian hat (true v = (0.1, 0.2), remodelling rate 0.05), same call, same printed summary.  The
-movie/overlay rendering of the original (matplotlib + ffmpeg) is presentation only and is left out.
+translating Gaussian hat (true v = (0.1, 0.2), remodelling rate 0.05), same calls, same printed summary.  The
+six-panel overlay movie of the original is written as well (``--movie``; .gif through pillow, the reference writes
+.mp4 where ffmpeg is installed).
 
-    python examples/simple_test_with_data_on_boundary.py        (needs an MI355X)
+    python examples/simple_test_with_data_on_boundary.py [--movie]        (needs an MI355X)
 """
 import os
 import sys
@@ -26,6 +27,13 @@ def simple_test_with_data_on_boundary():
     movie = np.stack((first_frame, second_frame))
     result = optical_flow.variational_optical_flow(movie, delta_x=delta_x, delta_t=1.0, speed_alpha=1.0,
                                                    remodelling_alpha=10000.0, smoothing_sigma=None)
+    if "--movie" in sys.argv:
+        import matplotlib
+        matplotlib.use("Agg")
+        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "output")
+        os.makedirs(out, exist_ok=True)
+        optical_flow.make_joint_overlay_movie(result, os.path.join(out, "simple_example_joint_result.gif"), autoscale=True,
+                                              arrow_scale=0.5, arrow_boxsize=4, dpi=100)
     print('mean and max final v_x are')
     print(np.mean(result['v_x']))
     print(np.max(result['v_x']))
