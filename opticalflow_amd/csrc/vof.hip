@@ -594,7 +594,7 @@ int gmres_buffers(vof_ctx* c, int want_m) {
 // Restarted, right-preconditioned GMRES on the pairs that are not converged yet: x = x_0 + M (V_k y), M = one
 // multigrid cycle (float64 vectors), restart from the true residual b - A x.  `iterations` keeps counting Krylov steps
 // (one cycle application each) on top of the BiCGStab iterations already spent.
-int gmres_phase(vof_ctx* c, int np) {
+int gmres_phase(vof_ctx* c, int np, int* handed_over) {
     const vof_params& P = c->prm;
     hipStream_t s = c->stream;
     const size_t len = 3 * c->L[0].npts;
@@ -606,6 +606,7 @@ int gmres_phase(vof_ctx* c, int np) {
     int nact = count_active(c, np);
     if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
     if (nact == 0) return 0;
+    *handed_over = nact;
     if (!c->gm_V) {
         int rc = gmres_buffers(c, P.gmres_restart > 0 ? P.gmres_restart : 100);
         if (rc == -3) { c->err.clear(); return 0; }   // no room: leave the pairs unconverged (reported per pair)
@@ -745,13 +746,24 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
           VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, (const VT*)c->kz, c->kr, c->kt, c->krh, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
-    if (P.krylov_method != 0)
-        if (int rc = gmres_phase(c, np)) return rc;
-    // independent residual (OF.py:1150-1151)
-    c->cur_units = np;
-    int nb3 = residual_d(c, c->kx, c->kb, c->kt, np, nullptr, 1);
-    if (!nb3) { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); nb3 = c->nblk; }
-    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, nb3, c->active, P.rtol, P.max_iterations); }
+    // independent residual (OF.py:1150-1151): ||b - A x|| recomputed from x for every pair
+    auto independent_residual = [&]() -> int {
+        c->cur_units = np;
+        int nb3 = residual_d(c, c->kx, c->kb, c->kt, np, nullptr, 1);
+        if (!nb3) { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); nb3 = c->nblk; }
+        { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, nb3, c->active, P.rtol, P.max_iterations); }
+        HIPCHK(hipGetLastError());
+        return 0;
+    };
+    if (int rc = independent_residual()) return rc;
+    if (P.krylov_method != 0) {
+        // GMRES takes the pairs BiCGStab left unconverged, and those whose recursively updated residual met the
+        // tolerance while the true one does not (the usual drift of BiCGStab at tight tolerances)
+        int handed_over = 0;
+        if (int rc = gmres_phase(c, np, &handed_over)) return rc;
+        if (handed_over)
+            if (int rc = independent_residual()) return rc;
+    }
     // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
     { Prof p(c, VOF_K_FUNCTIONALS, 0);
       k_functionals<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, P.speed_alpha,

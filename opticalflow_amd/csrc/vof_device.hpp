@@ -967,11 +967,16 @@ struct GmresState {
     int pad;
 };
 
-// active = cycle = pair still to be solved (not converged, iterations left); clears stale BiCGStab breakdown flags
+// active = cycle = pair still to be solved (true residual above the tolerance, iterations left)
 __global__ void k_gm_begin(PairScalars* __restrict__ sc, int* __restrict__ active, int* __restrict__ cycle, int np, int max_it) {
     int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= np) return;
-    int on = (!sc[pair].converged && sc[pair].iterations < max_it && sc[pair].bnorm2 > 0.0) ? 1 : 0;
+    PairScalars& s = sc[pair];
+    // rnorm2 is the independent residual here.  Not converged, or "converged" by the recursive residual while the true
+    // one misses the tolerance by more than 50 % (a marginal miss is not worth allocating the basis for)
+    bool need = !s.converged || s.rnorm2 > 2.25 * s.tol2;
+    int on = (need && s.iterations < max_it && s.bnorm2 > 0.0) ? 1 : 0;
+    if (on) s.converged = 0;
     active[pair] = on;
     cycle[pair] = on;
 }
