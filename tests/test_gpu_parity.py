@@ -399,3 +399,28 @@ def test_seeded_random_configurations_against_oracle(of, case):
     check_fields(res, ref, 1e-6, keys=("v_x", "v_y", "remodelling", "speed"))
     for key in ("L1_functional", "remodelling_functional", "speed_functional"):
         assert res[key] == pytest.approx(ref[key], rel=1e-5, abs=1e-10)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("VOF_FUZZ_CASES_MEDIUM", "10"))))
+def test_seeded_random_medium_sizes_by_independent_residual(of, case):
+    """As above at sizes the direct oracle is too slow for (up to ~400 pixels a side, several strips / bands per image):
+    the CPU-evaluated residual of the reference's operator (OF.py:1150-1151) must meet the requested tolerance for
+    every pair, whatever the solver options."""
+    rng = np.random.default_rng(5000 + case)
+    n_i, n_j = int(rng.integers(60, 400)), int(rng.integers(60, 400))
+    T = int(rng.integers(2, 5))
+    movie = orc.make_texture_stack(max(n_i, n_j), T, seed=100 + case)[:, :n_i, :n_j]
+    alpha, beta = float(10 ** rng.uniform(-0.3, 1.5)), float(10 ** rng.uniform(1.0, 4.0))
+    quirks = bool(case % 4 != 0)
+    opts = dict(krylov_method=["auto", "gmres"][case % 2], coarse_precision=["float32", "float64"][(case // 2) % 2],
+                vcycle_precision=["float64", "float32", "auto"][case % 3], w_cycle_level=[None, -1, (1, 2), 2][case % 4],
+                max_pairs_in_flight=[None, 2][case % 2])
+    res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, reference_quirks=quirks, rtol=1e-8,
+                                      return_stats=True, **opts)
+    assert res["stats"]["converged"].all(), (res["stats"], opts)
+    for k in range(T - 1):
+        xi = np.stack([res["v_x"][k], res["v_y"][k], res["remodelling"][k]])[:, 1:-1, 1:-1]
+        b = orc.rhs_interior(movie[k], movie[k + 1], quirks)
+        rr = np.linalg.norm(b - orc.apply_operator_interior(movie[k], xi, alpha, beta, quirks)) / np.linalg.norm(b)
+        assert rr <= 1.6e-8, (k, rr, opts)
+        assert rr == pytest.approx(res["stats"]["relative_residual"][k], rel=1e-3)
