@@ -128,3 +128,35 @@ def test_result_dictionary_survives_np_save(of, tmp_path):
                          "converged", "L1_functional", "remodelling_functional", "speed_functional"}
     np.testing.assert_array_equal(back["v_x"], res["v_x"])
     of.make_joint_overlay_movie(back, str(tmp_path / "joint.gif"), autoscale=True, arrow_scale=0.5, arrow_boxsize=4, dpi=30)
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("VOF_FUZZ_CASES_SWEEP", "6"))))
+def test_seeded_random_sweeps_and_subsampling(of, case):
+    """Seeded sweep over movie shapes, grid shapes, batch sizes (several combinations per batch / one / chunked movie),
+    blur and units: the native parameter sweep equals per-combination solves + numpy statistics, and the device gather
+    equals numpy slicing."""
+    import torch
+    rng = np.random.default_rng(9000 + case)
+    n_i, n_j, T = int(rng.integers(8, 90)), int(rng.integers(8, 90)), int(rng.integers(2, 6))
+    movie = orc.make_texture_stack(max(n_i, n_j, 16), T, seed=case)[:, :n_i, :n_j] * [1.0, 255.0][case % 2]
+    scale2 = [1.0, 255.0 ** 2][case % 2]
+    sa = scale2 * 10 ** rng.uniform(0.0, 1.5, int(rng.integers(1, 4)))
+    ra = 10 ** rng.uniform(1.0, 4.0, int(rng.integers(1, 4)))
+    kw = dict(delta_x=float(rng.uniform(0.3, 2.0)), delta_t=float(rng.uniform(0.5, 2.0)), rtol=1e-10,
+              smoothing_sigma=[None, float(rng.uniform(0.6, 2.0))][case % 2])
+    B = [None, T - 1, 1, 2 * (T - 1) + 1][case % 4]
+    r = of.vary_regularisation(movie, sa, ra, max_pairs_in_flight=B, **kw)
+    for i, a in enumerate(sa):
+        for j, b in enumerate(ra):
+            one = of.variational_optical_flow(movie, speed_alpha=a, remodelling_alpha=b, **kw)
+            np.testing.assert_allclose(r["speed_means"][i, j], np.mean(one["speed"]), rtol=1e-8)
+            np.testing.assert_allclose(r["speed_variances"][i, j], np.var(one["speed"]), rtol=1e-7)
+            np.testing.assert_allclose(r["remodelling_variances"][i, j], np.var(one["remodelling"]), rtol=1e-7)
+            np.testing.assert_allclose(r["functional"][i, j], one["L1_functional"] + one["speed_functional"]
+                                       + one["remodelling_functional"], rtol=1e-8)
+            assert r["converged"][i, j] == one["converged"]
+    box = int(rng.integers(1, 9))
+    dev = {k: (torch.as_tensor(v, device="cuda:0") if isinstance(v, np.ndarray) else v) for k, v in one.items()}
+    for got, want in zip(of.subsample_velocities_for_visualisation(dev, arrow_boxsize=box),
+                         orc.subsample_velocities_for_visualisation(one, arrow_boxsize=box)):
+        np.testing.assert_array_equal(got, want)
