@@ -74,7 +74,8 @@ struct vof_ctx {
     double* st_out[4] = {nullptr, nullptr, nullptr, nullptr};
     double* st_out2[4] = {nullptr, nullptr, nullptr, nullptr};   // second output set (copy / solve overlap of the host API)
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_solved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_solved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr}, ev_uploaded[2] = {nullptr, nullptr};
+    double* st_movie2 = nullptr;                                 // second frame buffer (upload of the next batch under the solve)
     double *blur_tmp = nullptr, *blur_w = nullptr, *blur_io = nullptr;   // Gaussian blur scratch (lazy)
     // GMRES fallback (allocated on first use): basis vectors V_0..V_m (each B * len0), per-pair state, partials, flags
     double* gm_V = nullptr;
@@ -889,6 +890,7 @@ void vof_destroy(vof_ctx* c) {
     for (int i = 0; i < 2; ++i) {
         if (c->ev_solved[i]) hipEventDestroy(c->ev_solved[i]);
         if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_uploaded[i]) hipEventDestroy(c->ev_uploaded[i]);
     }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1009,10 +1011,12 @@ static int ensure_staging(vof_ctx* c, bool double_buffer) {
     if (double_buffer && !c->st_out2[0]) {
         for (int i = 0; i < 4; ++i)
             if (int rc = dev_alloc(c, &c->st_out2[i], (size_t)c->B * fs)) return rc;
+        if (int rc = dev_alloc(c, &c->st_movie2, (size_t)(c->B + 1) * fs)) return rc;
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             HIPCHK(hipEventCreateWithFlags(&c->ev_solved[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
         }
     }
     return 0;
@@ -1027,13 +1031,35 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
     HIPCHK(hipSetDevice(c->device));
     const size_t fs = frame_stride(c);
     const int P = n_frames - 1;
-    const bool multi = P > c->B;                       // more than one batch: overlap copies with the next solve
+    const bool multi = P > c->B;                       // more than one batch: overlap the copies with the solves
     if (int rc = ensure_staging(c, multi)) return rc;
-    // Pageable host-to-device copies run at ~2 GB/s on this platform, pinned ones at ~55 GB/s: pin the caller's
-    // movie in place for the duration of the call (0.04 s/GB); fall back to the pageable path if that fails.
+    // Batch schedule: full batches, and the remainder split so that the LAST batch is small - its device-to-host copies
+    // are the only ones that cannot hide under a solve.
+    struct Batch { int k0, np; };
+    std::vector<Batch> batches;
+    for (int k0 = 0; k0 < P;) {
+        int np = std::min(c->B, P - k0);
+        const int rest = P - k0;
+        if (multi && rest <= c->B && rest > 48) np = rest - std::max(16, rest / 4);   // e.g. 127 -> 96 + 31
+        batches.push_back({k0, np});
+        k0 += np;
+    }
+    const int nb = (int)batches.size();
+    // Pageable host-to-device copies run at ~2 GB/s on this platform, pinned ones at ~55 GB/s: the caller's movie is
+    // pinned in place for the duration of the call (0.04 s/GB) - the frames of the first batch right away, the rest by a
+    // helper thread while the first batch is solved.  The split point is page aligned so that the two registrations do
+    // not share a page.  Unpinned parts fall back to pageable copies.
+    const char* mbase = (const char*)movie;
     const size_t movie_bytes = (size_t)n_frames * fs * sizeof(double);
-    const bool pinned = hipHostRegister((void*)movie, movie_bytes, hipHostRegisterDefault) == hipSuccess;
-    if (!pinned) (void)hipGetLastError();
+    size_t split = movie_bytes;
+    if (nb > 1) {
+        size_t want = (size_t)(batches[0].np + 1) * fs * sizeof(double);
+        size_t addr = ((size_t)(uintptr_t)mbase + want + 4095) & ~(size_t)4095;
+        split = std::min(movie_bytes, addr - (size_t)(uintptr_t)mbase);
+    }
+    const bool pinned_a = hipHostRegister((void*)mbase, split, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned_a) (void)hipGetLastError();
+    bool pinned_b = false;
     // Freshly allocated output arrays (np.empty) are not resident yet: first-touch page faults would serialise with
     // the device-to-host copies (0.6 s for 8 GB).  Helper threads prepare them while the GPU solves the first batch
     // (the arrays are outputs: every byte is overwritten below): with several batches they are pinned in place
@@ -1042,6 +1068,12 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
     const size_t out_bytes = (size_t)P * fs * sizeof(double);
     bool out_pinned[4] = {false, false, false, false};
     std::vector<std::thread> helpers;
+    std::thread movie_helper;
+    if (split < movie_bytes)
+        movie_helper = std::thread([&pinned_b, mbase, split, movie_bytes, dev = c->device]() {
+            if (hipSetDevice(dev) == hipSuccess &&
+                hipHostRegister((void*)(mbase + split), movie_bytes - split, hipHostRegisterDefault) == hipSuccess) pinned_b = true;
+        });
     for (int i = 0; i < 4; ++i)
         if (outs[i])
             helpers.emplace_back([ptr = (volatile char*)outs[i], out_bytes, multi, dev = c->device, flag = &out_pinned[i]]() {
@@ -1051,41 +1083,67 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
                 if (out_bytes) ptr[out_bytes - 1] = 0;
             });
     auto join_helpers = [&]() { for (auto& t : helpers) if (t.joinable()) t.join(); };
+    auto fail_msg = [&](const char* what, hipError_t e) { c->err = std::string(what) + ": " + hipGetErrorString(e); return -2; };
     int rc_all = 0;
-    int batch = 0;
-    for (int k0 = 0; k0 < P && !rc_all; k0 += c->B, ++batch) {
-        const int np = std::min(c->B, P - k0);
-        const int set = multi ? (batch & 1) : 0;
-        double** so = set ? c->st_out2 : c->st_out;
-        hipError_t e = hipMemcpyAsync(c->st_movie, movie + (size_t)k0 * fs, (size_t)(np + 1) * fs * sizeof(double),
-                                      hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { c->err = std::string("H2D copy failed: ") + hipGetErrorString(e); rc_all = -2; break; }
-        if (multi && batch >= 2) {                     // this output set is free once its previous copies are done
-            if (hipStreamWaitEvent(c->stream, c->ev_copied[set], 0) != hipSuccess) { c->err = "stream wait failed"; rc_all = -2; break; }
+    double* frames_buf[2] = {c->st_movie, multi ? c->st_movie2 : c->st_movie};
+    auto upload = [&](int bi, hipStream_t st) {   // frames k0 .. k0 + np of batch bi; a copy never straddles the two pinned regions
+        const Batch& bt = batches[bi];
+        const size_t o0 = (size_t)bt.k0 * fs * sizeof(double), o1 = o0 + (size_t)(bt.np + 1) * fs * sizeof(double);
+        char* dst = (char*)frames_buf[bi & 1];
+        hipError_t e = hipSuccess;
+        if (o0 < split) e = hipMemcpyAsync(dst, mbase + o0, std::min(o1, split) - o0, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && o1 > split) {
+            const size_t a = std::max(o0, split);
+            e = hipMemcpyAsync(dst + (a - o0), mbase + a, o1 - a, hipMemcpyHostToDevice, st);
         }
-        int rc = solve_batch(c, c->st_movie, np, so[0], so[1], so[2], so[3], stats ? stats + k0 : nullptr);
+        return e;
+    };
+    {
+        hipError_t e = upload(0, c->stream);
+        if (e != hipSuccess) rc_all = fail_msg("H2D copy failed", e);
+    }
+    for (int bi = 0; bi < nb && !rc_all; ++bi) {
+        const Batch& bt = batches[bi];
+        const int set = bi & 1;
+        double** so = (multi && set) ? c->st_out2 : c->st_out;
+        hipError_t e;
+        if (bi + 1 < nb) {   // frames of the next batch: uploaded on the copy stream while this batch is solved
+            if (movie_helper.joinable()) movie_helper.join();
+            // its buffer was last read by batch bi - 1
+            if (bi >= 1 && (e = hipStreamWaitEvent(c->copy_stream, c->ev_solved[(bi + 1) & 1], 0)) != hipSuccess) { rc_all = fail_msg("stream wait failed", e); break; }
+            if ((e = upload(bi + 1, c->copy_stream)) != hipSuccess ||
+                (e = hipEventRecord(c->ev_uploaded[(bi + 1) & 1], c->copy_stream)) != hipSuccess) { rc_all = fail_msg("H2D copy failed", e); break; }
+        }
+        if (bi > 0 && (e = hipStreamWaitEvent(c->stream, c->ev_uploaded[set], 0)) != hipSuccess) { rc_all = fail_msg("stream wait failed", e); break; }
+        if (multi && bi >= 2 && (e = hipStreamWaitEvent(c->stream, c->ev_copied[set], 0)) != hipSuccess) {   // output set free again
+            rc_all = fail_msg("stream wait failed", e);
+            break;
+        }
+        int rc = solve_batch(c, frames_buf[set], bt.np, so[0], so[1], so[2], so[3], stats ? stats + bt.k0 : nullptr);
         if (rc) { rc_all = rc; break; }
         join_helpers();
         hipStream_t cs = multi ? c->copy_stream : c->stream;
         if (multi) {
-            if (hipEventRecord(c->ev_solved[set], c->stream) != hipSuccess ||
-                hipStreamWaitEvent(cs, c->ev_solved[set], 0) != hipSuccess) { c->err = "event record failed"; rc_all = -2; break; }
+            if ((e = hipEventRecord(c->ev_solved[set], c->stream)) != hipSuccess ||
+                (e = hipStreamWaitEvent(cs, c->ev_solved[set], 0)) != hipSuccess) { rc_all = fail_msg("event record failed", e); break; }
         }
         for (int i = 0; i < 4 && !rc_all; ++i)
             if (outs[i]) {
-                e = hipMemcpyAsync(outs[i] + (size_t)k0 * fs, so[i], (size_t)np * fs * sizeof(double), hipMemcpyDeviceToHost, cs);
-                if (e != hipSuccess) { c->err = std::string("D2H copy failed: ") + hipGetErrorString(e); rc_all = -2; }
+                e = hipMemcpyAsync(outs[i] + (size_t)bt.k0 * fs, so[i], (size_t)bt.np * fs * sizeof(double), hipMemcpyDeviceToHost, cs);
+                if (e != hipSuccess) rc_all = fail_msg("D2H copy failed", e);
             }
         if (multi) {
-            if (!rc_all && hipEventRecord(c->ev_copied[set], cs) != hipSuccess) { c->err = "event record failed"; rc_all = -2; }
-        } else if (hipStreamSynchronize(c->stream) != hipSuccess && !rc_all) { c->err = "stream synchronize failed"; rc_all = -2; }
+            if (!rc_all && (e = hipEventRecord(c->ev_copied[set], cs)) != hipSuccess) rc_all = fail_msg("event record failed", e);
+        } else if ((e = hipStreamSynchronize(c->stream)) != hipSuccess && !rc_all) rc_all = fail_msg("stream synchronize failed", e);
     }
     join_helpers();
+    if (movie_helper.joinable()) movie_helper.join();
     if (multi && hipStreamSynchronize(c->copy_stream) != hipSuccess && !rc_all) { c->err = "copy stream synchronize failed"; rc_all = -2; }
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc_all) { c->err = "stream synchronize failed"; rc_all = -2; }
     for (int i = 0; i < 4; ++i)
         if (out_pinned[i]) (void)hipHostUnregister((void*)outs[i]);
-    if (pinned) (void)hipHostUnregister((void*)movie);
+    if (pinned_a) (void)hipHostUnregister((void*)mbase);
+    if (pinned_b) (void)hipHostUnregister((void*)(mbase + split));
     return rc_all;
 }
 

@@ -1,0 +1,15 @@
+"""Wall time of the drop-in call (1024^2 x 256, numpy in, numpy out) in a clean process.  GPU box only."""
+import os, sys, time, gc
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from opticalflow_amd import optical_flow as of
+from opticalflow_amd.synthetic import texture_stack_numpy
+n, T = 1024, 256
+base = texture_stack_numpy(n, 9, seed=1)
+movie = np.concatenate([base] * 29)[:T].copy()
+for rep in range(4):
+    t0 = time.time()
+    r = of.variational_optical_flow(movie, remodelling_alpha=1e4)
+    dt = time.time() - t0
+    print(f"drop-in call {rep}: {dt:.3f} s = {(T-1)/dt:.0f} pairs/s, converged {r['converged']}", flush=True)
+    t0 = time.time(); del r; gc.collect(); print(f"   freeing the result: {time.time()-t0:.3f} s", flush=True)
