@@ -160,3 +160,23 @@ def test_seeded_random_sweeps_and_subsampling(of, case):
     for got, want in zip(of.subsample_velocities_for_visualisation(dev, arrow_boxsize=box),
                          orc.subsample_velocities_for_visualisation(one, arrow_boxsize=box)):
         np.testing.assert_array_equal(got, want)
+
+
+def test_host_entry_point_optional_outputs_and_batch_schedule():
+    """vof_solve_stack_host with stats == NULL and speed == NULL, one batch and several (uploads of the next batch and
+    downloads of the previous one overlap the solves; uneven last batch): same fields as the plain call."""
+    import ctypes as C
+    from opticalflow_amd import _native
+    movie = np.ascontiguousarray(orc.make_texture_stack(72, 60, seed=31)[:, :, :65])    # 59 pairs
+    p = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e3, rtol=1e-9)
+    with _native.Solver(72, 65, 59) as s:
+        ref = s.solve_host(movie, p)
+    for B in (59, 50, 7, 1):                                                     # 1 / 2 (37 + 13 split) / many batches
+        with _native.Solver(72, 65, B) as s:
+            out = [np.full((59, 72, 65), np.nan) for _ in range(3)]
+            rc = s.lib.vof_solve_stack_host(s.h, _native._ptr(movie), 60, C.byref(p), _native._ptr(out[0]), _native._ptr(out[1]),
+                                            _native._ptr(out[2]), None, None)
+            assert rc == 0
+            for got, want in zip(out, ref[:3]):
+                assert np.isfinite(got).all()
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
