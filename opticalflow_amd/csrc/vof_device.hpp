@@ -964,7 +964,7 @@ struct GmresState {
     double c[GM_MAXM + 2];         // coefficients of the current Gram-Schmidt pass
     double scale;                  // 1 / norm of the vector to normalise next
     int k;                         // columns built in this cycle
-    int pad;
+    int est_converged;             // the cycle ended because the residual estimate met the tolerance
 };
 
 // active = cycle = pair still to be solved (true residual above the tolerance, iterations left)
@@ -976,7 +976,7 @@ __global__ void k_gm_begin(PairScalars* __restrict__ sc, int* __restrict__ activ
     // one misses the tolerance by more than 50 % (a marginal miss is not worth allocating the basis for)
     bool need = !s.converged || s.rnorm2 > 2.25 * s.tol2;
     int on = (need && s.iterations < max_it && s.bnorm2 > 0.0) ? 1 : 0;
-    if (on) s.converged = 0;
+    if (on) { s.converged = 0; s.rho = INFINITY; }   // rho: true residual^2 at the start of the previous cycle
     active[pair] = on;
     cycle[pair] = on;
 }
@@ -994,6 +994,12 @@ __global__ void k_gm_init(GmresState* __restrict__ st, PairScalars* __restrict__
     if (rn2 <= s.tol2) { s.converged = 1; active[pair] = 0; cycle[pair] = 0; return; }
     if (s.iterations >= max_it || !isfinite(rn2)) { active[pair] = 0; cycle[pair] = 0; return; }
     GmresState& q = st[pair];
+    // The previous cycle ended because its residual ESTIMATE met the tolerance, yet the true residual has not even halved:
+    // the tolerance is below the attainable accuracy ~ eps ||A|| ||x|| / ||b|| of this pair - stop and report instead of
+    // cycling up to max_iterations.  (A cycle that ends at the restart length is never cut short: slow is not stagnant.)
+    if (s.rho < INFINITY && q.est_converged && rn2 >= 0.25 * s.rho) { active[pair] = 0; cycle[pair] = 0; return; }
+    q.est_converged = 0;
+    s.rho = rn2;
     double beta = sqrt(rn2);
     q.g[0] = beta;
     q.scale = 1.0 / beta;
@@ -1126,6 +1132,7 @@ __global__ void k_gm_givens(GmresState* __restrict__ st, PairScalars* __restrict
     s.rnorm2 = q.g[j + 1] * q.g[j + 1];
     s.iterations += 1;
     // the estimate equals the true residual norm in exact arithmetic; the next cycle starts from the true residual
+    if (s.rnorm2 <= s.tol2) q.est_converged = 1;
     if (s.rnorm2 <= s.tol2 || !(hn > 0.0) || !(d > 0.0) || s.iterations >= max_it || !isfinite(s.rnorm2)) active[pair] = 0;
 }
 
