@@ -180,3 +180,30 @@ def test_host_entry_point_optional_outputs_and_batch_schedule():
             for got, want in zip(out, ref[:3]):
                 assert np.isfinite(got).all()
                 np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("VOF_FUZZ_CASES_BLUR", "8"))))
+def test_seeded_random_blur_and_device_mode(of, case):
+    """Seeded sweep over shapes, dtypes and sigmas: the device blur equals scipy's filter (the reference's skimage call)
+    to 4 ulp of the data range, and the device-resident mode equals the host mode bit for bit."""
+    import scipy.ndimage
+    import torch
+    rng = np.random.default_rng(12000 + case)
+    T, n_i, n_j = int(rng.integers(1, 6)), int(rng.integers(4, 150)), int(rng.integers(4, 150))
+    dtype = [np.float64, np.uint8, np.uint16, np.float32][case % 4]
+    top = {np.float64: 1.0, np.uint8: 255, np.uint16: 4095, np.float32: 100.0}[dtype]
+    movie = (rng.random((T, n_i, n_j)) * top).astype(dtype)
+    sigma = float(rng.uniform(0.3, 6.0))
+    got = of.blur_movie(movie, sigma)
+    want = np.stack([scipy.ndimage.gaussian_filter(f.astype(np.float64), sigma, mode="nearest", truncate=4.0) for f in movie])
+    assert got.shape == movie.shape and got.dtype == np.float64
+    np.testing.assert_allclose(got, want, rtol=0, atol=4 * np.finfo(np.float64).eps * float(top))
+    if T >= 2:
+        kw = dict(speed_alpha=float(top) ** 2 * 2.0, remodelling_alpha=float(10 ** rng.uniform(1, 3)), smoothing_sigma=[None, sigma][case % 2],
+                  max_pairs_in_flight=[None, 1][case % 2])
+        host = of.variational_optical_flow(movie, **kw)
+        dev = of.variational_optical_flow(torch.as_tensor(movie.astype(np.float64) if dtype == np.uint16 else movie, device="cuda:0"),
+                                          output="torch", **kw)
+        for k in ("v_x", "v_y", "speed", "remodelling", "blurred_data"):
+            np.testing.assert_array_equal(dev[k].cpu().numpy(), host[k], err_msg=k)
+        assert dev["converged"] == host["converged"] and dev["L1_functional"] == host["L1_functional"]
