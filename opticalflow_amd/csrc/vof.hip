@@ -1062,8 +1062,8 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
     bool pinned_b = false;
     // Freshly allocated output arrays (np.empty) are not resident yet: first-touch page faults would serialise with
     // the device-to-host copies (0.6 s for 8 GB).  Helper threads prepare them while the GPU solves the first batch
-    // (the arrays are outputs: every byte is overwritten below): with several batches they are pinned in place
-    // (which faults them in) so that the copies are truly asynchronous; with one batch they are only touched.
+    // (the arrays are outputs: every byte is overwritten below): they are pinned in place (which faults them in), so
+    // that the copies run at the pinned rate and asynchronously; arrays below 1 MB are only touched.
     double* outs[4] = {v_x, v_y, remodelling, speed};
     const size_t out_bytes = (size_t)P * fs * sizeof(double);
     bool out_pinned[4] = {false, false, false, false};
@@ -1074,10 +1074,11 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
             if (hipSetDevice(dev) == hipSuccess &&
                 hipHostRegister((void*)(mbase + split), movie_bytes - split, hipHostRegisterDefault) == hipSuccess) pinned_b = true;
         });
+    const bool pin_outputs = out_bytes >= ((size_t)1 << 20);   // pageable device-to-host copies can drop to ~2 GB/s
     for (int i = 0; i < 4; ++i)
         if (outs[i])
-            helpers.emplace_back([ptr = (volatile char*)outs[i], out_bytes, multi, dev = c->device, flag = &out_pinned[i]]() {
-                if (multi && hipSetDevice(dev) == hipSuccess &&
+            helpers.emplace_back([ptr = (volatile char*)outs[i], out_bytes, pin_outputs, dev = c->device, flag = &out_pinned[i]]() {
+                if (pin_outputs && hipSetDevice(dev) == hipSuccess &&
                     hipHostRegister((void*)ptr, out_bytes, hipHostRegisterDefault) == hipSuccess) { *flag = true; return; }
                 for (size_t o = 0; o < out_bytes; o += 4096) ptr[o] = 0;
                 if (out_bytes) ptr[out_bytes - 1] = 0;

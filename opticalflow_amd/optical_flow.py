@@ -8,16 +8,65 @@ The solve always runs on an MI355X through libvof.so; there is no CPU path in th
 """
 from __future__ import annotations
 
+import atexit
+import contextlib
+import threading
 import time
 
 import numpy as np
 
 from . import _native
 
+# ---------------------------------------------------------------------------------------------------------
+# One native context (device workspace) is kept between calls: creating / destroying tens of GB of device memory costs
+# 0.15-1.9 s per call, more than the solve of a whole stack.  It is re-used when the image size and the device match and
+# its batch is large enough, replaced otherwise, and released by ``release_device_memory()`` or at interpreter exit.
+# A context serves one thread at a time: a second thread calling concurrently gets a private, short-lived context.
+# ---------------------------------------------------------------------------------------------------------
+_cache_lock = threading.Lock()
+_cache = {"key": None, "solver": None}
+
+
+@contextlib.contextmanager
+def _device_context(n_i, n_j, pairs, device, exact=False):
+    device = int(device)
+    if not _cache_lock.acquire(blocking=False):
+        with _native.Solver(n_i, n_j, pairs, device=device) as solver:
+            yield solver
+        return
+    try:
+        solver = _cache["solver"]
+        # exact: the caller asked for this batch size (max_pairs_in_flight): honour it instead of a larger cached batch
+        if (solver is None or not solver.h or _cache["key"] != (n_i, n_j, device) or solver.max_pairs < pairs
+                or (exact and solver.max_pairs != pairs)):
+            release_device_memory(_locked=True)
+            solver = _native.Solver(n_i, n_j, pairs, device=device)
+            _cache["key"], _cache["solver"] = (n_i, n_j, device), solver
+        try:
+            yield solver
+        except BaseException:
+            release_device_memory(_locked=True)      # do not keep a context whose call failed half-way
+            raise
+    finally:
+        _cache_lock.release()
+
+
+def release_device_memory(_locked=False):
+    """Free the device workspace kept between calls (it is re-created on the next call)."""
+    if not _locked:
+        with _cache_lock:
+            return release_device_memory(_locked=True)
+    if _cache["solver"] is not None:
+        _cache["solver"].close()
+    _cache["key"], _cache["solver"] = None, None
+
+
+atexit.register(release_device_memory)
+
 __all__ = ["variational_optical_flow", "vary_regularisation", "make_fake_data_frame", "blur_movie",
            "format_elapsed_time", "apply_constant_boundary_condition", "choose_pairs_in_flight",
            "subsample_velocities_for_visualisation", "costum_imshow", "make_velocity_overlay_movie",
-           "make_joint_overlay_movie"]
+           "make_joint_overlay_movie", "release_device_memory"]
 
 
 def make_fake_data_frame(x_position, y_position, sigma=1.0, width=20.0, include_noise=False, dimension=1000):
@@ -55,7 +104,7 @@ def blur_movie(movie, smoothing_sigma, device=0, _solver=None):
     frames = np.ascontiguousarray(movie, dtype=np.float64)
     if _solver is not None:
         return _solver.blur_host(frames, taps)
-    with _native.Solver(max(4, movie.shape[1]), max(4, movie.shape[2]), 1, device=device) as solver:
+    with _device_context(max(4, movie.shape[1]), max(4, movie.shape[2]), 1, device) as solver:
         if (solver.n_i, solver.n_j) != movie.shape[1:]:
             raise ValueError("frames must be at least 4x4")
         return solver.blur_host(frames, taps)
@@ -189,24 +238,24 @@ def variational_optical_flow(movie,
     movie = np.asarray(movie).astype(np.float64)                       # OF.py:769
     if movie.ndim != 3:
         raise ValueError("movie must be a 3-D array (frames, x, y)")
-    if smoothing_sigma is not None:                                     # OF.py:770-773
-        movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma, device=device, _solver=_solver)
-    else:
-        movie_to_analyse = movie
     T, N_i, N_j = movie.shape
     if T < 2:
         raise ValueError("movie needs at least two frames")
     params = _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                             use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
                             multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart)
+    exact = max_pairs_in_flight is not None
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
     t0 = time.time()
-    if _solver is not None:      # a caller-owned context (vary_regularisation re-uses one workspace for all solves)
-        v_x, v_y, remodelling, speed, stats = _solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
-    else:
-        with _native.Solver(N_i, N_j, max_pairs_in_flight, device=device) as solver:
-            v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+    # a caller-owned context (_solver) or the module's cached one; blur and solve share it
+    with (contextlib.nullcontext(_solver) if _solver is not None
+          else _device_context(N_i, N_j, max_pairs_in_flight, device, exact)) as solver:
+        if smoothing_sigma is not None:                                 # OF.py:770-773
+            movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma, device=device, _solver=solver)
+        else:
+            movie_to_analyse = movie
+        v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
     if verbose:
         m, s, ms = format_elapsed_time(time.time() - t0)
         print(f"Elapsed time for solve: {m} minutes, {s} seconds, {ms} milliseconds")
@@ -247,11 +296,12 @@ def _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_i
     T, N_i, N_j = movie.shape
     if T < 2:
         raise ValueError("movie needs at least two frames")
+    exact = max_pairs_in_flight is not None
     if max_pairs_in_flight is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, int(device))
     out = [torch.empty((T - 1, N_i, N_j), dtype=torch.float64, device=dev) for _ in range(4)]
     torch.cuda.synchronize(dev)          # the library launches on its own stream
-    with _native.Solver(N_i, N_j, max_pairs_in_flight, device=int(device)) as solver:
+    with _device_context(N_i, N_j, max_pairs_in_flight, device, exact) as solver:
         if smoothing_sigma is not None:                                                  # OF.py:770-773
             taps = gaussian_taps(smoothing_sigma)
             movie_to_analyse = torch.empty_like(movie)
@@ -314,7 +364,7 @@ def vary_regularisation(movie,
     # short movies: several combinations share one batch as "virtual pairs" (see vof_vary_regularisation_host)
     n_comb = max(1, len(speed_alpha_values) * len(remodelling_alpha_values))
     pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, (T - 1) * n_comb, kw["device"])
-    with _native.Solver(N_i, N_j, pairs, device=kw["device"]) as solver:
+    with _device_context(N_i, N_j, pairs, kw["device"], kw["max_pairs_in_flight"] is not None) as solver:
         rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,
                                               remodelling_alpha_values, taps)
     if kw["verbose"]:
@@ -368,7 +418,7 @@ def subsample_velocities_for_visualisation(flow_result, iteration=None, arrow_bo
     if hasattr(fields[0], "data_ptr") and fields[0].is_cuda:
         import torch
         sub = []
-        with _native.Solver(n_x, n_y, 1, device=fields[0].device.index) as solver:
+        with _device_context(n_x, n_y, 1, fields[0].device.index) as solver:
             for f in fields:
                 out = torch.empty((n_pairs, nbx, nby), dtype=torch.float64, device=f.device)
                 torch.cuda.synchronize(f.device)
