@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--nu-post-coarse", type=int, default=1)
     ap.add_argument("--w-cycle-level", type=int, default=None, help="-1: V-cycle; l: level l visits level l+1 twice")
     ap.add_argument("--w-cycle-visits", type=int, default=None)
+    ap.add_argument("--warm-start-stride", type=int, default=None, help="0/1: every pair starts from the constant initial fields (library default: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational mixed-precision variant run")
     ap.add_argument("--no-allgather", action="store_true")
@@ -164,6 +165,8 @@ def main():
         params.w_cycle_level = args.w_cycle_level
     if args.w_cycle_visits is not None:
         params.w_cycle_visits = args.w_cycle_visits
+    if args.warm_start_stride is not None:
+        params.warm_start_stride = args.warm_start_stride
     solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
@@ -253,6 +256,7 @@ def main():
                    "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
                    "sweeps": [args.nu_pre, args.nu_post, args.nu_pre_coarse, args.nu_post_coarse],
                    "w_cycle_level": int(params.w_cycle_level), "w_cycle_visits": int(params.w_cycle_visits),
+                   "warm_start_stride": int(params.warm_start_stride),
                    "allgather": gathered is not None, "gather_chunks": n_chunks,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),
@@ -278,8 +282,11 @@ def main():
                     "relres_max": float(stv["relative_residual"].max()), "converged": bool(stv["converged"].all())}
         common = dict(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol, nu_pre=args.nu_pre, nu_post=args.nu_post,
                       nu_pre_coarse=args.nu_pre_coarse, nu_post_coarse=args.nu_post_coarse,
-                      w_cycle_level=int(params.w_cycle_level), w_cycle_visits=int(params.w_cycle_visits))
+                      w_cycle_level=int(params.w_cycle_level), w_cycle_visits=int(params.w_cycle_visits),
+                      warm_start_stride=int(params.warm_start_stride))
+        cold = dict(common, warm_start_stride=0)
         out["variants"] = {
+            "constant_initial_fields_for_every_pair": timed(_native.default_params(vcycle_precision=0, coarse_precision=1, **cold)),
             "all_float64_storage": timed(_native.default_params(vcycle_precision=0, coarse_precision=0, **common)),
             "float32_stencils_auto_vectors": timed(_native.default_params(vcycle_precision=2, coarse_precision=1, **common)),
         }

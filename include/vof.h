@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 103 /* 0.1.3 */
+#define VOF_VERSION 104 /* 0.1.4 */
 
 typedef struct vof_ctx vof_ctx;
 
@@ -55,7 +55,10 @@ typedef struct vof_params {
     int32_t gmres_restart;     /* restart length (default 100, at most 128); the basis takes (restart + 1) float64 vectors per pair in
                                   flight and is capped at half of the free device memory when the fallback first runs */
     int32_t fallback_after;    /* BiCGStab iterations before the fallback (default 25) */
-    int32_t reserved;
+    int32_t warm_start_stride; /* vof_solve_stack_dev, stacks of >= 2 * stride pairs: every stride-th pair is solved first from the
+                                  constant initial fields, the others start from the solution of their nearest solved neighbour
+                                  (the reference warm-starts pair k from pair k-1, OF.py:803-806).  Default 3; 0 or 1: every pair
+                                  starts from the constant initial fields.  Same stopping rule either way */
 } vof_params;
 
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */

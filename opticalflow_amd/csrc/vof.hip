@@ -58,6 +58,12 @@ struct vof_ctx {
     bool vfloat = false;    // V-cycle vectors stored as float32 (arithmetic stays FP64)
     const PairParam* pp = nullptr;   // per-pair (alpha, beta, frame) overrides of the current batch ("virtual pairs") or nullptr
     PairParam* pp_buf = nullptr;     // device storage for them (B entries, lazy)
+    // warm start (two-phase solve of a stack): interior solutions of the phase-1 pairs, and per pair of the current
+    // batch the index of the saved solution to start from (nullptr: constant initial fields)
+    double* warm_x = nullptr;
+    size_t warm_cap = 0;
+    int* warm_src = nullptr;
+    const int* guess_src = nullptr;
     double* partials = nullptr;
     int nblk = 0;
     PairScalars* sc = nullptr;
@@ -697,7 +703,10 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     // initial guess (OF.py:799-802: constants, in pixels/frame) and initial residual
     double sx = P.delta_t / P.delta_x;
     bool zero_guess = (P.initial_v_x == 0.0 && P.initial_v_y == 0.0 && P.initial_remodelling == 0.0);
-    if (zero_guess) {
+    if (c->guess_src) {   // warm start from the solution of a neighbouring, already solved pair (cf. OF.py:803-806)
+        { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len); k_gather_guess<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->warm_x, c->guess_src, len); }
+        residual_d(c, c->kx, c->kb, c->kr, np, nullptr);
+    } else if (zero_guess) {
         HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)np * len * sizeof(double), s));
         HIPCHK(hipMemcpyAsync(c->kr, c->kb, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
     } else {
@@ -771,7 +780,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
                                                   P.remodelling_alpha, P.reference_quirks, c->kx, c->partials, c->pp);
       k_sum3<<<np, 64, 0, s>>>(c->partials, c->nblk, c->func3); }
     { Prof p(c, VOF_K_FINALIZE, 0);
-      k_finalize<<<grid2d(c->Ni, c->Nj, np), blk2d, 0, s>>>(c->kx, f.ni, f.nj, P.delta_x / P.delta_t, vx, vy, gm, speed); }
+      k_finalize<<<grid2d(c->Ni, c->Nj, np), blk2d, 0, s>>>(c->kx, f.ni, f.nj, P.delta_x / P.delta_t, vx, vy, gm, speed, c->pp); }
     HIPCHK(hipGetLastError());
     if (stats) {
         HIPCHK(hipMemcpyAsync(c->h_sc, c->sc, np * sizeof(PairScalars), hipMemcpyDeviceToHost, s));
@@ -803,6 +812,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->krylov_method < 0 || p->krylov_method > 2) { c->err = "krylov_method must be 0, 1 or 2"; return -1; }
     if (p->gmres_restart < 0 || p->gmres_restart > GM_MAXM) { c->err = "gmres_restart must be in [0, 128]"; return -1; }
     if (p->fallback_after < 0) { c->err = "fallback_after must be >= 0"; return -1; }
+    if (p->warm_start_stride < 0) { c->err = "warm_start_stride must be >= 0"; return -1; }
     c->prm = *p;
     // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
     c->vfloat = p->vcycle_precision >= 1 && c->fused && c->L.size() > 1;
@@ -836,6 +846,7 @@ void vof_default_params(vof_params* p) {
     p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)
     p->krylov_method = 2;          // BiCGStab (the reference's 'bcgs'); stragglers are finished by restarted GMRES
     p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
+    p->warm_start_stride = 3;      // vof_solve_stack_dev: every 3rd pair first, the others start from their solved neighbour
     p->fallback_after = 25;        // BiCGStab iterations before the fallback (the benchmark regimes need 3-17)
 }
 
@@ -979,6 +990,57 @@ int vof_create(vof_ctx** out, int device_id, int n_i, int n_j, int max_pairs_in_
     return 0;
 }
 
+// Two-phase solve of a stack with warm starts (the reference warm-starts pair k from pair k-1, OF.py:803-806, which
+// serialises the pairs; here every stride-th pair is solved first from the constant initial fields, then all the others
+// start from the solution of their nearest solved neighbour).  Pairs are addressed through the PairParam table
+// (frame / output slot), so both phases are ordinary batches.
+static int solve_stack_two_phase(vof_ctx* c, const double* movie, int P, double* v_x, double* v_y, double* remodelling,
+                                 double* speed, vof_pair_stats* stats, int stride) {
+    const vof_params prm = c->prm;
+    const size_t len = 3 * c->L[0].npts;
+    const int B = c->B;
+    std::vector<int> first, rest;
+    for (int k = 0; k < P; ++k) (k % stride == 0 ? first : rest).push_back(k);
+    const int n1 = (int)first.size();
+    if (!c->pp_buf) { if (int rc = dev_alloc(c, &c->pp_buf, (size_t)B)) return rc; }
+    if (!c->warm_src) { if (int rc = dev_alloc(c, &c->warm_src, (size_t)B)) return rc; }
+    if (c->warm_cap < (size_t)n1 * len) {
+        if (int rc = dev_alloc(c, &c->warm_x, (size_t)n1 * len)) return rc;
+        c->warm_cap = (size_t)n1 * len;
+    }
+    std::vector<PairParam> hp((size_t)B);
+    std::vector<int> hsrc((size_t)B);
+    std::vector<vof_pair_stats> st((size_t)B);
+    auto run = [&](const std::vector<int>& list, bool phase2) -> int {
+        for (size_t o = 0; o < list.size(); o += (size_t)B) {
+            const int np = (int)std::min<size_t>((size_t)B, list.size() - o);
+            for (int i = 0; i < np; ++i) {
+                const int k = list[o + i];
+                hp[i] = PairParam{prm.speed_alpha, prm.remodelling_alpha, k, k};
+                hsrc[i] = std::min((k + stride / 2) / stride, n1 - 1);
+            }
+            HIPCHK(hipStreamSynchronize(c->stream));   // the host tables are re-used
+            HIPCHK(hipMemcpyAsync(c->pp_buf, hp.data(), (size_t)np * sizeof(PairParam), hipMemcpyHostToDevice, c->stream));
+            if (phase2) HIPCHK(hipMemcpyAsync(c->warm_src, hsrc.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            c->pp = c->pp_buf;
+            c->guess_src = phase2 ? c->warm_src : nullptr;
+            int rc = solve_batch(c, movie, np, v_x, v_y, remodelling, speed, stats ? st.data() : nullptr);
+            c->pp = nullptr;
+            c->guess_src = nullptr;
+            if (rc) return rc;
+            if (!phase2)
+                HIPCHK(hipMemcpyAsync(c->warm_x + o * len, c->kx, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            if (stats)
+                for (int i = 0; i < np; ++i) stats[list[o + i]] = st[i];
+        }
+        return 0;
+    };
+    if (int rc = run(first, false)) return rc;
+    if (int rc = run(rest, true)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof_params* p, double* v_x, double* v_y,
                         double* remodelling, double* speed, vof_pair_stats* stats) {
     if (!c) return -1;
@@ -988,6 +1050,8 @@ int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof
     HIPCHK(hipSetDevice(c->device));
     size_t fs = frame_stride(c);
     int P = n_frames - 1;
+    if (p->warm_start_stride > 1 && P >= 2 * p->warm_start_stride)
+        return solve_stack_two_phase(c, movie, P, v_x, v_y, remodelling, speed, stats, p->warm_start_stride);
     for (int k0 = 0; k0 < P; k0 += c->B) {
         int np = std::min(c->B, P - k0);
         int rc = solve_batch(c, movie + (size_t)k0 * fs, np, v_x + (size_t)k0 * fs, v_y + (size_t)k0 * fs,
@@ -1310,7 +1374,7 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
             const int g = std::min(G, n_comb - t0), np = g * P;
             for (int u = 0; u < g; ++u)
                 for (int k = 0; k < P; ++k)
-                    hp[(size_t)u * P + k] = PairParam{speed_alphas[(t0 + u) / n_ra], remodelling_alphas[(t0 + u) % n_ra], k, 0};
+                    hp[(size_t)u * P + k] = PairParam{speed_alphas[(t0 + u) / n_ra], remodelling_alphas[(t0 + u) % n_ra], k, u * P + k};
             if (hipStreamSynchronize(c->stream) != hipSuccess) {   // hp is re-used: the previous upload must have completed
                 c->err = "stream synchronize failed";
                 return fail(-2);

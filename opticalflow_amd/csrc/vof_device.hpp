@@ -35,8 +35,8 @@ struct PairScalars {
 // Kernels take a `const PairParam* pp`; nullptr (the normal case) = kernel arguments / frame index = pair index.
 struct PairParam {
     double alpha, beta;
-    int frame;
-    int pad;
+    int frame;   // index of the pair's first frame in the movie
+    int out;     // index of the pair's slot in the output stacks
 };
 
 __device__ __forceinline__ int fold(int t, int n) { return t < 0 ? 1 : (t >= n ? n - 2 : t); }
@@ -886,14 +886,15 @@ __global__ void k_scalar(PairScalars* __restrict__ sc, const double* __restrict_
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_finalize(const double* __restrict__ x, int ni, int nj, double vscale,
                                                  double* __restrict__ vx, double* __restrict__ vy,
-                                                 double* __restrict__ gm, double* __restrict__ speed) {
+                                                 double* __restrict__ gm, double* __restrict__ speed,
+                                                 const PairParam* __restrict__ pp) {
     int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     int Ni = ni + 2, Nj = nj + 2;
     if (i >= Ni || j >= Nj) return;
     size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     size_t idx = (size_t)fold(i - 1, ni) * nj + fold(j - 1, nj);
     double u = x[off + idx] * vscale, w = x[off + npts + idx] * vscale, g = x[off + 2 * npts + idx];
-    size_t o = (size_t)pair * Ni * Nj + (size_t)i * Nj + j;
+    size_t o = (size_t)(pp ? pp[pair].out : pair) * Ni * Nj + (size_t)i * Nj + j;
     vx[o] = u;
     vy[o] = w;
     gm[o] = g;
@@ -1148,6 +1149,15 @@ __global__ void k_gm_solve_y(GmresState* __restrict__ st, const int* __restrict_
         double dgl = q.R[(size_t)i * GM_MAXM + i];
         q.y[i] = dgl != 0.0 ? v / dgl : 0.0;
     }
+}
+
+// warm start: x[pair] = saved[src[pair]] (interior solution of an already solved neighbouring pair)
+__global__ __launch_bounds__(RBLK) void k_gather_guess(double* __restrict__ x, const double* __restrict__ saved,
+                                                       const int* __restrict__ src, size_t len) {
+    int pair = blockIdx.y;
+    const double* from = saved + (size_t)src[pair] * len;
+    double* to = x + (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) to[i] = from[i];
 }
 
 // x += z (z V-cycle output, float64)

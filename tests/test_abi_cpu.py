@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_default_params(lib):
     from opticalflow_amd import _native
-    assert lib.vof_version() == 103
+    assert lib.vof_version() == 104
     p = _native.default_params()
     # the reference's solver settings: OF.py:718-719, 1120
     assert (p.speed_alpha, p.remodelling_alpha, p.rtol, p.max_iterations) == (1.0, 1000.0, 1e-6, 1000)

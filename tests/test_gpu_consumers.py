@@ -207,3 +207,34 @@ def test_seeded_random_blur_and_device_mode(of, case):
         for k in ("v_x", "v_y", "speed", "remodelling", "blurred_data"):
             np.testing.assert_array_equal(dev[k].cpu().numpy(), host[k], err_msg=k)
         assert dev["converged"] == host["converged"] and dev["L1_functional"] == host["L1_functional"]
+
+
+def test_warm_started_stack_solve_equals_cold_solve():
+    """vof_solve_stack_dev solves every 3rd pair first and starts the others from their solved neighbour (the reference
+    warm-starts pair k from pair k-1, OF.py:803-806): same stopping rule, same answer to the accuracy that rule implies,
+    fewer iterations; outputs and statistics land in the natural pair order, also when a phase needs several batches."""
+    import torch
+    from opticalflow_amd import _native
+    from opticalflow_amd.synthetic import texture_stack_torch
+    n, T = 96, 30
+    dev = torch.device("cuda", 0)
+    movie = texture_stack_torch(n, T, 4, dev)
+    outs = {}
+    for label, stride, B in (("cold", 0, 29), ("warm", 3, 29), ("warm, small batches", 3, 4), ("warm, stride 8", 8, 29)):
+        p = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9, warm_start_stride=stride)
+        f = [torch.empty((T - 1, n, n), dtype=torch.float64, device=dev) for _ in range(4)]
+        torch.cuda.synchronize()
+        with _native.Solver(n, n, B) as s:
+            st = s.solve_dev(movie, T, p, *f)
+        assert st["converged"].all() and st["relative_residual"].max() <= 1.5e-9
+        outs[label] = ([t.cpu().numpy() for t in f], st)
+    cold_fields, cold_st = outs["cold"]
+    for label in ("warm", "warm, small batches", "warm, stride 8"):
+        fields, st = outs[label]
+        for a, b in zip(fields, cold_fields):
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
+        assert st["iterations"].sum() < cold_st["iterations"].sum()
+        np.testing.assert_allclose(st["L1_functional"], cold_st["L1_functional"], rtol=1e-5)
+    # the pairs solved first (every 3rd) are untouched by the warm start: bit-identical to the cold solve
+    np.testing.assert_array_equal(outs["warm"][0][0][::3], cold_fields[0][::3])
+    np.testing.assert_array_equal(outs["warm"][1]["iterations"][::3], cold_st["iterations"][::3])
