@@ -1050,7 +1050,11 @@ int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof
     HIPCHK(hipSetDevice(c->device));
     size_t fs = frame_stride(c);
     int P = n_frames - 1;
-    if (p->warm_start_stride > 1 && P >= 2 * p->warm_start_stride)
+    // two phases double the latency-bound part of a solve (set-up, small coarse levels): worth it once the first phase
+    // alone keeps the chip busy (>= 16 Mpixel of frame pairs; measured: 128^2 x 8 loses 45 %, 512^2 x 64 is neutral,
+    // 1024^2 x 129 gains 22 %)
+    if (p->warm_start_stride > 1 && P >= 2 * p->warm_start_stride &&
+        (double)(P / p->warm_start_stride) * (double)c->Ni * (double)c->Nj >= 16e6)
         return solve_stack_two_phase(c, movie, P, v_x, v_y, remodelling, speed, stats, p->warm_start_stride);
     for (int k0 = 0; k0 < P; k0 += c->B) {
         int np = std::min(c->B, P - k0);

@@ -154,7 +154,7 @@ def _float64_copy(a, n_threads=4):
 
 def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                    use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
-                   multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None):
+                   multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None, warm_start_stride=None):
     # krylov_method may be a tuple ("auto", fallback_after): BiCGStab iterations before GMRES takes over
     fallback_after = None
     if isinstance(krylov_method, (tuple, list)):
@@ -184,6 +184,8 @@ def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x
         params.gmres_restart = int(gmres_restart)
     if fallback_after is not None:
         params.fallback_after = fallback_after
+    if warm_start_stride is not None:
+        params.warm_start_stride = int(warm_start_stride)
     return params
 
 
@@ -209,6 +211,7 @@ def variational_optical_flow(movie,
                              w_cycle_level=None,
                              krylov_method="auto",
                              gmres_restart=None,
+                             warm_start_stride=None,
                              verbose=False,
                              return_stats=False,
                              output="numpy",
@@ -239,6 +242,8 @@ def variational_optical_flow(movie,
         ``krylov_method`` ("bicgstab": the reference's KSP type, OF.py:1081; "gmres": restarted GMRES with the same
         preconditioner and stopping rule; "auto" (default): BiCGStab, and GMRES(``gmres_restart``, default 100) for the
         pairs that have not converged after 25 iterations - the grad-div dominated regimes),
+        ``warm_start_stride`` (device-resident mode only: every n-th pair is solved first, the others start from their
+        solved neighbour, cf. OF.py:803-806; default 3, 0 = every pair from the constant initial fields),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals), ``output`` ("numpy": host arrays as in the reference; "torch": ``movie`` may be a
         torch tensor already on the device and every array of the result stays on the device as a float64 torch
@@ -250,7 +255,7 @@ def variational_optical_flow(movie,
                                                     speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y,
                                                     initial_remodelling, use_direct_solver, rtol, max_iterations,
                                                     reference_quirks, coarse_precision, vcycle_precision, multigrid_sweeps,
-                                                    w_cycle_level, krylov_method, gmres_restart), delta_x, delta_t)
+                                                    w_cycle_level, krylov_method, gmres_restart, warm_start_stride), delta_x, delta_t)
     if output != "numpy":
         raise ValueError("output must be 'numpy' or 'torch'")
     movie = _float64_copy(np.asarray(movie))                           # OF.py:769

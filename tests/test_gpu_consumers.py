@@ -216,11 +216,11 @@ def test_warm_started_stack_solve_equals_cold_solve():
     import torch
     from opticalflow_amd import _native
     from opticalflow_amd.synthetic import texture_stack_torch
-    n, T = 96, 30
+    n, T = 768, 90          # first phase 29 pairs x 0.59 Mpixel = 17 Mpixel: above the threshold of the two-phase solve
     dev = torch.device("cuda", 0)
     movie = texture_stack_torch(n, T, 4, dev)
     outs = {}
-    for label, stride, B in (("cold", 0, 29), ("warm", 3, 29), ("warm, small batches", 3, 4), ("warm, stride 8", 8, 29)):
+    for label, stride, B in (("cold", 0, 89), ("warm", 3, 89), ("warm, small batches", 3, 13), ("warm, stride 2", 2, 89)):
         p = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9, warm_start_stride=stride)
         f = [torch.empty((T - 1, n, n), dtype=torch.float64, device=dev) for _ in range(4)]
         torch.cuda.synchronize()
@@ -229,12 +229,13 @@ def test_warm_started_stack_solve_equals_cold_solve():
         assert st["converged"].all() and st["relative_residual"].max() <= 1.5e-9
         outs[label] = ([t.cpu().numpy() for t in f], st)
     cold_fields, cold_st = outs["cold"]
-    for label in ("warm", "warm, small batches", "warm, stride 8"):
+    for label in ("warm", "warm, small batches", "warm, stride 2"):
         fields, st = outs[label]
         for a, b in zip(fields, cold_fields):
             assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
         assert st["iterations"].sum() < cold_st["iterations"].sum()
         np.testing.assert_allclose(st["L1_functional"], cold_st["L1_functional"], rtol=1e-5)
-    # the pairs solved first (every 3rd) are untouched by the warm start: bit-identical to the cold solve
-    np.testing.assert_array_equal(outs["warm"][0][0][::3], cold_fields[0][::3])
+    # the pairs solved first (every 3rd) do not see the warm start: same iterations, same fields up to the summation
+    # order of the reductions (the band height of the streaming kernels follows the batch size)
+    np.testing.assert_allclose(outs["warm"][0][0][::3], cold_fields[0][::3], rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(outs["warm"][1]["iterations"][::3], cold_st["iterations"][::3])
