@@ -226,9 +226,9 @@ def variational_optical_flow(movie,
     reference), ``L1_functional``, ``remodelling_functional``, ``speed_functional``.
 
     Differences, all opt-in or invisible at the reference's tolerance:
-      * all pairs are solved concurrently from the same constant initial guess instead of
-        warm-starting pair k from pair k-1 (OF.py:803-806); the converged answer is the same to
-        solver tolerance;
+      * all pairs are solved concurrently instead of warm-starting pair k from pair k-1 (OF.py:803-806): from the same
+        constant initial guess, or (device-resident mode, large stacks) every 3rd pair first and the others from their
+        solved neighbour; the converged answer is the same to solver tolerance;
       * ``use_direct_solver=True`` (SuperLU in the reference, OF.py:1146-1147) is honoured as "solve
         to rtol=1e-11" on the GPU;
       * keyword-only extras: ``rtol`` (default 1e-6 = OF.py:1120), ``max_iterations`` (1000),
