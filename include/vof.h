@@ -55,7 +55,7 @@ typedef struct vof_params {
     int32_t gmres_restart;     /* restart length (default 100, at most 128); the basis takes (restart + 1) float64 vectors per pair in
                                   flight and is capped at half of the free device memory when the fallback first runs */
     int32_t fallback_after;    /* BiCGStab iterations before the fallback (default 25) */
-    int32_t warm_start_stride; /* vof_solve_stack_dev, stacks whose first phase is >= 16 Mpixel of pairs: every stride-th pair is solved first from the
+    int32_t warm_start_stride; /* vof_solve_stack_dev / _host (per batch), stacks whose first phase is >= 16 Mpixel of pairs: every stride-th pair is solved first from the
                                   constant initial fields, the others start from the solution of their nearest solved neighbour
                                   (the reference warm-starts pair k from pair k-1, OF.py:803-806).  Default 3; 0 or 1: every pair
                                   starts from the constant initial fields.  Same stopping rule either way */

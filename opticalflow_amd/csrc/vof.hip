@@ -1041,6 +1041,27 @@ static int solve_stack_two_phase(vof_ctx* c, const double* movie, int P, double*
     return 0;
 }
 
+// Solve pairs 0 .. P-1 of a device-resident range of frames (P <= any size): two-phase warm start when it pays, plain
+// batches otherwise.  Outputs are indexed by the pair's position in the range.
+static int solve_range_dev(vof_ctx* c, const double* frames, int P, double* v_x, double* v_y, double* remodelling,
+                           double* speed, vof_pair_stats* stats) {
+    const int stride = c->prm.warm_start_stride;
+    const size_t fs = frame_stride(c);
+    // two phases double the latency-bound part of a solve (set-up, small coarse levels): worth it once the first phase
+    // alone keeps the chip busy (>= 16 Mpixel of frame pairs; measured: 128^2 x 8 loses 45 %, 512^2 x 64 is neutral,
+    // 1024^2 x 129 gains 22 %)
+    if (stride > 1 && P >= 2 * stride && (double)(P / stride) * (double)c->Ni * (double)c->Nj >= 16e6)
+        return solve_stack_two_phase(c, frames, P, v_x, v_y, remodelling, speed, stats, stride);
+    for (int k0 = 0; k0 < P; k0 += c->B) {
+        int np = std::min(c->B, P - k0);
+        int rc = solve_batch(c, frames + (size_t)k0 * fs, np, v_x + (size_t)k0 * fs, v_y + (size_t)k0 * fs,
+                             remodelling + (size_t)k0 * fs, speed ? speed + (size_t)k0 * fs : nullptr,
+                             stats ? stats + k0 : nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof_params* p, double* v_x, double* v_y,
                         double* remodelling, double* speed, vof_pair_stats* stats) {
     if (!c) return -1;
@@ -1048,21 +1069,7 @@ int vof_solve_stack_dev(vof_ctx* c, const double* movie, int n_frames, const vof
     if (n_frames < 2) { c->err = "need at least two frames"; return -1; }
     if (int rc = check_params(c, p)) return rc;
     HIPCHK(hipSetDevice(c->device));
-    size_t fs = frame_stride(c);
-    int P = n_frames - 1;
-    // two phases double the latency-bound part of a solve (set-up, small coarse levels): worth it once the first phase
-    // alone keeps the chip busy (>= 16 Mpixel of frame pairs; measured: 128^2 x 8 loses 45 %, 512^2 x 64 is neutral,
-    // 1024^2 x 129 gains 22 %)
-    if (p->warm_start_stride > 1 && P >= 2 * p->warm_start_stride &&
-        (double)(P / p->warm_start_stride) * (double)c->Ni * (double)c->Nj >= 16e6)
-        return solve_stack_two_phase(c, movie, P, v_x, v_y, remodelling, speed, stats, p->warm_start_stride);
-    for (int k0 = 0; k0 < P; k0 += c->B) {
-        int np = std::min(c->B, P - k0);
-        int rc = solve_batch(c, movie + (size_t)k0 * fs, np, v_x + (size_t)k0 * fs, v_y + (size_t)k0 * fs,
-                             remodelling + (size_t)k0 * fs, speed ? speed + (size_t)k0 * fs : nullptr,
-                             stats ? stats + k0 : nullptr);
-        if (rc) return rc;
-    }
+    if (int rc = solve_range_dev(c, movie, n_frames - 1, v_x, v_y, remodelling, speed, stats)) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1188,7 +1195,7 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
             rc_all = fail_msg("stream wait failed", e);
             break;
         }
-        int rc = solve_batch(c, frames_buf[set], bt.np, so[0], so[1], so[2], so[3], stats ? stats + bt.k0 : nullptr);
+        int rc = solve_range_dev(c, frames_buf[set], bt.np, so[0], so[1], so[2], so[3], stats ? stats + bt.k0 : nullptr);
         if (rc) { rc_all = rc; break; }
         join_helpers();
         hipStream_t cs = multi ? c->copy_stream : c->stream;

@@ -239,3 +239,24 @@ def test_warm_started_stack_solve_equals_cold_solve():
     # order of the reductions (the band height of the streaming kernels follows the batch size)
     np.testing.assert_allclose(outs["warm"][0][0][::3], cold_fields[0][::3], rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(outs["warm"][1]["iterations"][::3], cold_st["iterations"][::3])
+
+
+def test_host_entry_point_warm_start_per_batch():
+    """vof_solve_stack_host applies the same two-phase warm start inside each of its batches: equal to the cold solve to the
+    accuracy of the stopping rule, fewer iterations, statistics and fields in natural order across the batch schedule."""
+    from opticalflow_amd import _native
+    from opticalflow_amd.synthetic import texture_stack_numpy
+    n, T = 768, 100
+    movie = texture_stack_numpy(n, T, seed=6)
+    res = {}
+    for label, stride, B in (("cold", 0, 99), ("warm", 3, 99), ("warm, two batches", 3, 90)):   # 90 + 9 pairs: the small batch stays cold
+        p = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9, warm_start_stride=stride)
+        with _native.Solver(n, n, B) as s:
+            res[label] = s.solve_host(movie, p)
+        st = res[label][4]
+        assert st["converged"].all() and st["relative_residual"].max() <= 1.5e-9
+    for label in ("warm", "warm, two batches"):
+        for a, b in zip(res[label][:4], res["cold"][:4]):
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
+        assert res[label][4]["iterations"].sum() < res["cold"][4]["iterations"].sum()
+        np.testing.assert_allclose(res[label][4]["L1_functional"], res["cold"][4]["L1_functional"], rtol=1e-5)
