@@ -9,6 +9,9 @@ outputs resident in HBM.  For N > 1 each rank owns a contiguous shard of the sta
 timed step.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N --steps K --warmup W] [--size 1024 --frames 256]
+
+`python bench.py --gpus N` (N > 1) without a torch.distributed environment starts the N ranks itself (fresh child
+processes through torch.distributed.run, before anything touches the GPU) and relays rank 0's line.
 """
 import argparse
 import json
@@ -51,27 +54,68 @@ def largest_batch(n_pairs, per_pair_bytes, budget_bytes):
     return max(1, -(-n_pairs // n_batches))
 
 
-def cpu_baseline(size, seed):
-    """The reference's CPU algorithm (assembly OF.py:833-1072 + its direct-solver branch OF.py:1146-1147)
-    as restated by the oracle, timed on this host on a bounded sample."""
+def _cpu_pair(args):
+    """One frame pair through the oracle's assembly + direct solve (worker of the all-cores baseline)."""
+    size, seed, crop, k = args
     import numpy as np
     from oracle import vof_oracle as orc
+    movie = orc.make_texture_stack(size, 2, seed=seed, first_frame=k)[:, :crop, :crop]
+    t0 = time.time()
+    orc.variational_optical_flow(np.ascontiguousarray(movie), speed_alpha=1.0, remodelling_alpha=1e4)
+    return time.time() - t0
+
+
+def cpu_baseline(size, seed):
+    """The reference's CPU algorithm (assembly OF.py:833-1072 + its direct-solver branch OF.py:1146-1147) as restated by
+    the oracle, timed on this host on a bounded sample: first on ONE core (the reference is a single sequential process,
+    OF.py:1098 PETSc.COMM_SELF), then one pair per core on all the cores this process may use."""
+    import multiprocessing as mp
     crop = min(size, 256)
-    movie = orc.make_texture_stack(size, 5, seed=seed)[:, :crop, :crop]
+    pix_ratio = (size * size) / float(crop * crop)
     t0 = time.time()
     pairs = 0
-    while pairs < 4 and (pairs == 0 or time.time() - t0 < 12.0):      # ~10-30 s of CPU work
-        orc.variational_optical_flow(np.ascontiguousarray(movie[pairs:pairs + 2]), speed_alpha=1.0,
-                                     remodelling_alpha=1e4)
+    while pairs < 2 and (pairs == 0 or time.time() - t0 < 8.0):
+        _cpu_pair((size, seed, crop, pairs))
         pairs += 1
     dt = (time.time() - t0) / pairs
-    pix_ratio = (size * size) / float(crop * crop)
+    host_cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cores
+    workers = max(1, min(usable, 16))           # the GPU box gives one GPU's job a 16-core share
+    all_cores = None
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            t1 = time.time()
+            per = pool.map(_cpu_pair, [(size, seed, crop, k) for k in range(workers)])
+            wall = time.time() - t1
+        all_cores = {"value": workers / (wall * pix_ratio), "unit": "frame-pairs/s", "cores": workers,
+                     "seconds_wall": wall, "seconds_per_pair_mean": float(sum(per) / len(per)),
+                     "sample": f"{workers} pairs of the same {crop}x{crop} crop, one per process"}
+    except Exception as exc:      # noqa: BLE001 - the single-core figure stands on its own
+        all_cores = {"error": repr(exc)}
     return {"value": 1.0 / (dt * pix_ratio), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "host_cores": host_cores, "usable_cores": usable,
             "sample": f"{pairs} frame pair(s), {crop}x{crop} crop of the workload's first frames: sparse assembly + "
-                      f"SuperLU direct solve (the reference's use_direct_solver branch, OF.py:1146-1147) took "
-                      f"{dt:.1f} s per pair on 1 core; scaled linearly by pixel count to {size}x{size} "
-                      f"(optimistic for the CPU: fill-in is super-linear)",
-            "seconds_per_sample_pair": dt}
+                      f"SuperLU direct solve (the reference's use_direct_solver branch, OF.py:1146-1147; PETSc is not "
+                      f"installable on the box) took {dt:.1f} s per pair on 1 core; scaled linearly by pixel count to "
+                      f"{size}x{size} (optimistic for the CPU: fill-in is super-linear)",
+            "seconds_per_sample_pair": dt, "all_cores": all_cores}
+
+
+def selftest_launch(real_stdout):
+    """CPU check of the launcher path (tests/test_distributed_cpu.py): every rank joins a gloo group, the ranks agree on a
+    sum, rank 0 prints one JSON line.  Nothing here touches a GPU."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"selftest": "launch", "n_gpus": world, "sum": float(t.item())}) + "\n").encode())
+    dist.destroy_process_group()
 
 
 def main():
@@ -80,7 +124,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--frames", type=int, default=256, help="frames per rank (weak scaling)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per rank (weak scaling).  Default: 256 on one GPU (BASELINE configs[2]: 1024x1024x256), "
+                         "129 per rank on several (configs[3]: 1024 pairs of 1024x1024 over 8 GPUs = 128 pairs per rank)")
     ap.add_argument("--pairs-in-flight", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="float32", choices=["float64", "float32"])
@@ -89,22 +135,32 @@ def main():
     ap.add_argument("--nu-post", type=int, default=2)
     ap.add_argument("--nu-pre-coarse", type=int, default=1)
     ap.add_argument("--nu-post-coarse", type=int, default=1)
-    ap.add_argument("--w-cycle-level", type=int, default=None, help="-1: V-cycle; l: level l visits level l+1 twice")
+    ap.add_argument("--w-cycle-level", type=int, default=None, help="-1: V-cycle; l: level l visits level l+1 several times")
     ap.add_argument("--w-cycle-visits", type=int, default=None)
-    ap.add_argument("--warm-start-stride", type=int, default=None, help="0/1: every pair starts from the constant initial fields (library default: 8)")
+    ap.add_argument("--warm-start-stride", type=int, default=None, help="0/1: every pair starts from the constant initial fields (library default: 3)")
+    ap.add_argument("--wobble", type=float, default=0.0, help="time-varying flow of the synthetic stack (0: uniform translation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true", help="skip the informational mixed-precision variant run")
+    ap.add_argument("--no-variants", action="store_true", help="skip the informational variant runs")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-allgather", action="store_true")
-    ap.add_argument("--gather-chunks", type=int, default=0, help="chunks of the stack whose all-gather overlaps the next solve")
+    ap.add_argument("--gather-chunks", type=int, default=0, help="equal chunks of the rank's pairs whose all-gather overlaps the next solve (default: distributed.chunk_plan)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even at world size 1 (test)")
     ap.add_argument("--profile-table", action="store_true", help="print the per-kernel HIP-event table (stderr)")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner on the
+    # ---- `python bench.py --gpus N` started by hand: become the launcher of N fresh rank processes.  Nothing has
+    # touched the GPU (torch is not even imported) - the parent only relays rank 0's line and the exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from opticalflow_amd.distributed import launch_ranks
+        raise SystemExit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL and gloo print banners on the
     # first communicator): keep the real stdout aside and point fd 1 at stderr for everything else.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.selftest_launch:
+        return selftest_launch(real_stdout)
 
     import numpy as np
     import torch
@@ -114,8 +170,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N` or "
+                         f"under torch.distributed.run with --nproc-per-node N)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -130,32 +186,31 @@ def main():
 
     from opticalflow_amd import _native
     from opticalflow_amd.synthetic import texture_stack_torch
-    from opticalflow_amd.distributed import allgather_chunk
+    from opticalflow_amd.distributed import allgather_chunk, block_cyclic_range, chunk_plan
 
-    n, T = args.size, args.frames
+    n = args.size
+    T = args.frames or (256 if world == 1 else 129)
     P = T - 1
-    seed = {512: 0, 1024: 1, 2048: 3}.get(n, 1)
-    # this rank's shard of the (world * T)-frame stack; frames are generated on the device
-    movie = texture_stack_torch(n, T, seed, dev, first_frame=rank * (T - 1))
-    vx = torch.empty((P, n, n), dtype=torch.float64, device=dev)
-    vy = torch.empty_like(vx)
-    gm = torch.empty_like(vx)
-    sp = torch.empty_like(vx)
-    gathered = None
-    n_chunks = 1
-    if use_dist and not args.no_allgather:
-        # re-assembled stack, natural order: gathered[f][r * P + k] = field f of pair k of rank r
-        gathered = [torch.empty((world * P, n, n), dtype=torch.float64, device=dev) for _ in range(3)]
-        # the stack is solved in a few chunks so that the all-gather of chunk i (RCCL stream) overlaps the solve of
-        # chunk i+1 (solver stream)
-        n_chunks = args.gather_chunks if args.gather_chunks > 0 else next((d for d in (3, 4, 5, 2) if P % d == 0), 1)
-        if P % n_chunks:
-            n_chunks = 1
-    torch.cuda.synchronize()
-
+    seed = {512: 0, 1024: 1 if world == 1 else 2, 2048: 3}.get(n, 1)     # C2, C3 / C4, C5
+    gather = use_dist and not args.no_allgather
+    # Several ranks: the rank's P pairs are cut into chunks dealt block-cyclically over the global stack, so that the
+    # all-gather of chunk i lands in place (natural order) while chunk i+1 is solved; one rank: one chunk = the stack.
+    sizes = chunk_plan(P, args.gather_chunks) if gather else [P]
+    n_chunks = len(sizes)
     per_pair = _native.query_workspace(n, n, 1)
     free, total = _native.device_memory(local_rank)
-    B = args.pairs_in_flight or largest_batch(P // n_chunks, per_pair, 0.7 * free)
+    gathered_bytes = 3 * world * P * n * n * 8 if gather else 0
+    B = args.pairs_in_flight or largest_batch(max(sizes), per_pair, 0.7 * free - gathered_bytes)
+    solver = _native.Solver(n, n, B, device=local_rank)
+    # frames of every chunk (its pairs + one overlap frame), generated on the device by the HIP generator
+    movies, outs = [], []
+    for i in range(n_chunks):
+        g0, g1 = block_cyclic_range(rank, world, sizes, i) if gather else (rank * P, rank * P + P)
+        movies.append(texture_stack_torch(n, g1 - g0 + 1, seed, dev, first_frame=g0, solver=solver, wobble=args.wobble))
+        outs.append([torch.empty((g1 - g0, n, n), dtype=torch.float64, device=dev) for _ in range(4)])   # vx, vy, gm, speed
+    gathered = [torch.empty((world * P, n, n), dtype=torch.float64, device=dev) for _ in range(3)] if gather else None
+    torch.cuda.synchronize()
+
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
                                     coarse_precision={"float64": 0, "float32": 1}[args.coarse_precision],
                                     vcycle_precision={"float64": 0, "float32": 1, "auto": 2}[args.vcycle_precision],
@@ -167,22 +222,25 @@ def main():
         params.w_cycle_visits = args.w_cycle_visits
     if args.warm_start_stride is not None:
         params.warm_start_stride = args.warm_start_stride
-    solver = _native.Solver(n, n, B, device=local_rank)
     coarse_bytes = 8 if args.coarse_precision == "float64" else 4
 
-    def step():
-        if gathered is None:
-            return solver.solve_dev(movie, T, params, vx, vy, gm, sp, stats=True)   # syncs the solver's stream
-        cl = P // n_chunks
+    def step(pv=None, mv=None):
+        pv = pv or params
         works, stats_all = [], []
         for i in range(n_chunks):
-            a, b_ = i * cl, (i + 1) * cl
-            stats_all.append(solver.solve_dev(movie[a:b_ + 1], cl + 1, params, vx[a:b_], vy[a:b_], gm[a:b_], sp[a:b_],
-                                              stats=True))          # returns after the solver's stream has drained
-            for dst, src in zip(gathered, (vx, vy, gm)):
-                works.append(allgather_chunk(dst, src, a, b_, P))
+            m = (mv or movies)[i]
+            o = outs[i]
+            stats_all.append(solver.solve_dev(m, m.shape[0], pv, o[0], o[1], o[2], o[3], stats=True))
+            # solve_dev returns after the solver's stream has drained: the chunk's fields are final
+            if gathered is not None:
+                for dst, src in zip(gathered, o[:3]):
+                    works.append(allgather_chunk(dst, src, sizes, i))       # RCCL's stream, under the next solve
         for w in works:
             w.wait()
+        if works:
+            # the exchange is part of the step, and the next step's solver (its own stream) must not overwrite the
+            # fields RCCL is still reading
+            torch.cuda.current_stream().synchronize()
         return np.concatenate(stats_all)
 
     def barrier():
@@ -204,12 +262,17 @@ def main():
     # kernels); on tiny stacks the latency-bound set-up kernels (dense inversion, Galerkin products) can be larger
     with_bytes = [r for r in table if solver.profile_bytes(r[0], r[1]) > 0]
     dom = max(with_bytes or table, key=lambda r: r[3])
+    alg_total = sum(solver.profile_bytes(r[0], r[1]) for r in table)
+    counted_ms = sum(r[3] for r in with_bytes)
     if args.profile_table and rank == 0:
         for name, lvl, cnt, ms in sorted(table, key=lambda r: -r[3]):
             gb = solver.profile_bytes(name, lvl) / 1e9
             print(f"  {name:13s} L{lvl:<2d} launches {cnt:7d}  total {ms:10.3f} ms  avg {1e3 * ms / cnt:9.2f} us  "
                   f"{100 * ms / total_ms:5.1f}%  {gb / (ms * 1e-3) if gb else 0:8.0f} GB/s", file=sys.stderr)
+        print(f"  all kernels: {total_ms:.1f} ms of GPU time per warm-up step set, {alg_total / 1e9:.1f} GB algorithmic "
+              f"({alg_total / 1e9 / (total_ms * 1e-3):.0f} GB/s over all kernel time)", file=sys.stderr)
     dom_name, dom_level = dom[0], dom[1]
+    warm_steps = max(1, args.warmup)
     solver.profile_reset()
     solver.profile_filter(dom_name, dom_level)       # timed region: events only around the dominant kernel
 
@@ -241,23 +304,30 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     # the PMC passes were taken with all pairs of the stack in one batch; with chunked solves (multi-GPU overlap) a
     # launch processes fewer pairs and the per-launch traffic figure does not apply
-    if os.path.exists(tpath) and B >= P:
+    if os.path.exists(tpath) and B >= P and n_chunks == 1 and not args.wobble:
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(f"{dom_name}_L{dom_level}_{n}x{n}x{T}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    if world == 1:
+        workload = (f"{n}x{n}x{T} synthetic translating texture (seed {seed}), speed_alpha=1, remodelling_alpha=1e4, "
+                    f"rtol={args.rtol:g}, all {P} pairs solved to the stopping rule")
+    else:
+        workload = (f"{n}x{n}x{world * P + 1} synthetic translating texture (seed {seed}) over {world} GPUs "
+                    f"({P} pairs = {T} frames per GPU" + (", BASELINE configs[3]: 1024x1024x1024 over 8 GPUs" if (n, world, P) == (1024, 8, 128) else "")
+                    + f"), speed_alpha=1, remodelling_alpha=1e4, rtol={args.rtol:g}, all pairs solved to the stopping rule, "
+                    f"flow fields all-gathered to every GPU inside the step")
     out = {
         "metric": "frame-pairs/sec", "value": value, "unit": "frame-pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n}x{n}x{T} synthetic translating texture per GPU (seed {seed}), speed_alpha=1, "
-                               f"remodelling_alpha=1e4, rtol={args.rtol:g}, all {P} pairs solved to the stopping rule",
+        "config": {"workload": workload, "frames_per_gpu": T, "wobble": args.wobble,
                    "pairs_in_flight": B, "levels": solver.num_levels, "coarse_stencils": args.coarse_precision, "vcycle_vectors": args.vcycle_precision,
                    "sweeps": [args.nu_pre, args.nu_post, args.nu_pre_coarse, args.nu_post_coarse],
                    "w_cycle_level": int(params.w_cycle_level), "w_cycle_visits": int(params.w_cycle_visits),
                    "warm_start_stride": int(params.warm_start_stride),
-                   "allgather": gathered is not None, "gather_chunks": n_chunks,
+                   "allgather": gathered is not None, "gather_chunks": n_chunks, "chunk_sizes": sizes,
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),
                    "converged": bool(stats["converged"].all())},
@@ -265,17 +335,23 @@ def main():
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "launches": cnt, "pairs_per_launch": (units / cnt) if cnt else None, "avg_launch_us": 1e6 * avg_s if cnt else None,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "share_of_gpu_time": dom[3] / total_ms},
+                     "share_of_gpu_time": dom[3] / total_ms,
+                     # the whole solve, not only the dominant kernel: algorithmic bytes of every byte-counted launch of the
+                     # warm-up step(s) over the step time (HIP-event profile of the warm-up; set-up kernels count as time)
+                     "whole_solve": {"algorithmic_bytes_per_step": alg_total / warm_steps,
+                                     "achieved": alg_total / warm_steps / (1e-3 * 1e3 * dt / args.steps) / 1e9,
+                                     "frac": alg_total / warm_steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                     "kernel_time_share_with_byte_count": counted_ms / total_ms}},
     }
     if world == 1 and not use_dist and not args.no_variants:
-        # informational, not the headline: the same step with other storage precisions inside the preconditioner
-        # (headline = library defaults: float32 Galerkin stencils, float64 V-cycle vectors).  Arithmetic, Krylov
-        # vectors, stopping rule and results are float64 in all of them.
-        def timed(pv):
-            solver.solve_dev(movie, T, pv, vx, vy, gm, sp, stats=True)
+        # informational, not the headline: the same step with other settings (headline = library defaults: float32
+        # Galerkin stencils, float64 V-cycle vectors, two-phase warm start).  Arithmetic, Krylov vectors, stopping rule
+        # and results are float64 in all of them.
+        def timed(pv, mv=None):
+            step(pv, mv)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            stv = solver.solve_dev(movie, T, pv, vx, vy, gm, sp, stats=True)
+            stv = step(pv, mv)
             torch.cuda.synchronize()
             d = time.perf_counter() - t1
             return {"value": P / d, "unit": "frame-pairs/s", "iterations_mean": float(stv["iterations"].mean()),
@@ -290,12 +366,42 @@ def main():
             "all_float64_storage": timed(_native.default_params(vcycle_precision=0, coarse_precision=0, **common)),
             "float32_stencils_auto_vectors": timed(_native.default_params(vcycle_precision=2, coarse_precision=1, **common)),
         }
+        if not args.wobble:
+            # a less warm-start-friendly sibling of the headline input: the same texture with a time-varying flow
+            # (frame-to-frame step (0.3, 0.6) x (1 +- 0.3)), default settings
+            wob = [texture_stack_torch(n, T, seed, dev, first_frame=0, solver=solver, wobble=0.3)]
+            out["variants"]["time_varying_flow_wobble_0.3"] = timed(params, wob)
+            out["variants"]["time_varying_flow_wobble_0.3_cold"] = timed(_native.default_params(vcycle_precision=0, coarse_precision=1, **cold), wob)
+            del wob
+    if world == 1 and not use_dist and not args.no_end_to_end:
+        # end-to-end rate of the drop-in call, pageable numpy arrays in and out (the reference's
+        # contract), i.e. including the float64 copy, H2D of the movie and D2H of the four result stacks.  Never `value`.
+        from opticalflow_amd import optical_flow as of
+        movie_host = movies[0].cpu().numpy()
+        solver.close()
+        solver = None
+        torch.cuda.empty_cache()
+        e2e = []
+        for _ in range(2):          # the first call creates the cached device context
+            t1 = time.perf_counter()
+            r = of.variational_optical_flow(movie_host, speed_alpha=1.0, remodelling_alpha=1e4, return_stats=True)
+            e2e.append(time.perf_counter() - t1)
+            ok = bool(r["stats"]["converged"].all())
+            del r
+        of.release_device_memory()
+        out["end_to_end"] = {"value": P / e2e[-1], "unit": "frame-pairs/s", "seconds": e2e[-1], "seconds_first_call": e2e[0],
+                             "converged": ok,
+                             "what": "opticalflow_amd.optical_flow.variational_optical_flow(movie) with pageable numpy arrays "
+                                     "in and out: float64 copy, H2D, solve, D2H of v_x, v_y, speed, remodelling "
+                                     f"({movie_host.nbytes / 1e9:.1f} GB up, {4 * P * n * n * 8 / 1e9:.1f} GB down)"}
+        del movie_host
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, seed)
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    solver.close()
+    if solver is not None:
+        solver.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -23,12 +23,16 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 104 /* 0.1.4 */
+#define VOF_VERSION 200 /* 0.2.0: vof_params carries its own size and the ABI version */
 
 typedef struct vof_ctx vof_ctx;
 
-/* Solver parameters.  Defaults (vof_default_params) reproduce the reference's settings. */
+/* Solver parameters.  Defaults (vof_default_params) reproduce the reference's settings.
+ * ABI guard: the first two fields are filled in by vof_default_params and checked by every entry point that takes a
+ * vof_params (a binding compiled against another layout is rejected with an error instead of being read past its end). */
 typedef struct vof_params {
+    uint32_t struct_size;      /* sizeof(vof_params) of the header the caller was built with */
+    uint32_t abi_version;      /* VOF_VERSION of that header */
     double speed_alpha;        /* OF.py:718  */
     double remodelling_alpha;  /* OF.py:719  */
     double delta_x;            /* OF.py:716; velocities are returned in delta_x/delta_t units (OF.py:1189-1190) */
@@ -64,7 +68,9 @@ typedef struct vof_params {
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */
 typedef struct vof_pair_stats {
     int32_t iterations;        /* BiCGStab iterations used */
-    int32_t converged;         /* 1 if the stopping rule was met (OF.py:1135 solver.is_converged) */
+    int32_t converged;         /* 1 iff the INDEPENDENT residual below meets the stopping rule, ||b - A x||^2 <= rtol^2 ||b||^2
+                                  (OF.py:1135 solver.is_converged, OF.py:1120,1126), evaluated on the residual recomputed
+                                  from x after the solve - never on the solver's recursively updated residual */
     double relative_residual;  /* independent ||A x - b|| / ||b|| after the solve (OF.py:1151) */
     double L1_functional;      /* OF.py:1178-1180 */
     double speed_functional;   /* OF.py:1181-1182 (the true one; the dict-level bug is applied by the caller) */
@@ -79,7 +85,19 @@ enum vof_kernel_id {
 };
 
 int vof_version(void);
-void vof_default_params(vof_params* p);
+/* sizeof(vof_params) of the library (a binding asserts that its own struct has this size). */
+size_t vof_params_size(void);
+/* Fills *p with the defaults.  struct_size = sizeof(vof_params) as the CALLER declares it: if it differs from the
+ * library's, nothing is written and -1 is returned (a stale binding can neither be overrun nor half-initialised). */
+int vof_default_params(vof_params* p, size_t struct_size);
+
+/* Environment variables read once by vof_create (A/B experiment switches; results are identical, only speed changes):
+ *   VOF_SWEEP_GEO=AA|AB|BA|BB  strip geometry of the fused sweep on (level 0, stored levels); default AB
+ *   VOF_STREAM_APPLY=0         level-0 operator: simple kernel instead of the LDS-streaming one
+ *   VOF_FUSE_RESTRICT=0        level 0: separate residual and restriction kernels
+ *   VOF_FUSE_PROLONG=0         level 0: separate prolongation kernel instead of interpolating inside the first post-sweep
+ *   VOF_COARSE_TAIL=0          levels whose whole grid fits one workgroup: one launch per operation instead of the fused
+ *                              LDS-resident coarse-tail kernel */
 
 /* One context = one device = one host thread at a time.  Owns device workspaces for images of
  * (n_i, n_j) and up to max_pairs_in_flight frame pairs solved concurrently (batch dimension).
@@ -142,6 +160,13 @@ int vof_field_moments_dev(vof_ctx* ctx, const double* field_dev, size_t n, doubl
  * field stack (n_fields, n_i, n_j): out[k][a][b] = field[k][a*box + offset][b*box + offset], a < n_i / box,
  * b < n_j / box (the reference uses offset = round(box / 2)).  out_dev: (n_fields, n_i/box, n_j/box) doubles. */
 int vof_subsample_dev(vof_ctx* ctx, const double* field_dev, int n_fields, int box, int offset, double* out_dev);
+
+/* Benchmark harness (no counterpart in the reference; SURVEY.md section 8(d) fixes the recipe): n_frames frames of the
+ * exactly translating synthetic texture, written to device memory,
+ *   I_t(i, j) = clip(0.5 + scale * sum_k a_k cos(2 pi (f_k (i - ox_t) + g_k (j - oy_t)) / period + phi_k), 0, 1).
+ * mode_params: host, 4 * n_modes doubles (f, g, a, phi); frame_offsets: host, (ox_t, oy_t) per frame. */
+int vof_texture_stack_dev(vof_ctx* ctx, double* out_dev, int n_frames, const double* mode_params, int n_modes,
+                          const double* frame_offsets, double period, double scale);
 
 /* Smoother implementation: 1 (default) = fused streaming 4-colour sweep (one launch per sweep),
  * 0 = one launch per colour (the simple reference kernels, kept for A/B tests). */

@@ -19,7 +19,8 @@ K_NAMES = ["rhs", "apply0", "gs0", "gs", "residual", "restrict", "prolong", "gal
 
 
 class VofParams(C.Structure):
-    _fields_ = [("speed_alpha", C.c_double), ("remodelling_alpha", C.c_double), ("delta_x", C.c_double),
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+                ("speed_alpha", C.c_double), ("remodelling_alpha", C.c_double), ("delta_x", C.c_double),
                 ("delta_t", C.c_double), ("initial_v_x", C.c_double), ("initial_v_y", C.c_double),
                 ("initial_remodelling", C.c_double), ("rtol", C.c_double), ("max_iterations", C.c_int32),
                 ("nu_pre", C.c_int32), ("nu_post", C.c_int32), ("reference_quirks", C.c_int32),
@@ -52,7 +53,8 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); every symbol include/vof.h declares
 SIGNATURES = {
     "vof_version": (C.c_int, []),
-    "vof_default_params": (None, [C.POINTER(VofParams)]),
+    "vof_params_size": (C.c_size_t, []),
+    "vof_default_params": (C.c_int, [C.POINTER(VofParams), C.c_size_t]),
     "vof_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "vof_destroy": (None, [_vp]),
     "vof_last_error": (C.c_char_p, [_vp]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "vof_num_levels": (C.c_int, [_vp]),
     "vof_solve_stack_host": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), _vp, _vp, _vp, _vp, _vp]),
     "vof_solve_stack_dev": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), _vp, _vp, _vp, _vp, _vp]),
+    "vof_texture_stack_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_double, C.c_double]),
     "vof_bench_sweeps_dev": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), C.c_int]),
     "vof_blur_stack_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "vof_blur_stack_host": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
@@ -140,7 +143,8 @@ def load_library(path: str | None = None):
 def default_params(**overrides) -> VofParams:
     lib = load_library()
     p = VofParams()
-    lib.vof_default_params(C.byref(p))
+    if lib.vof_default_params(C.byref(p), C.sizeof(p)) != 0:
+        raise VofError(f"vof_params layout mismatch: binding {C.sizeof(p)} bytes, library {lib.vof_params_size()} bytes")
     for k, v in overrides.items():
         if not hasattr(p, k):
             raise TypeError(f"unknown solver parameter {k!r}")
@@ -271,6 +275,14 @@ class Solver:
         """out[k, a, b] = field[k, a*box + offset, b*box + offset] on device memory."""
         self._check(self.lib.vof_subsample_dev(self.h, _ptr(field), int(n_fields), int(box), int(offset), _ptr(out)),
                     "vof_subsample_dev")
+
+    def texture_stack_dev(self, out, n_frames, mode_params, frame_offsets, period, scale):
+        """Synthetic translating texture written to ``out`` (device, (n_frames, n_i, n_j))."""
+        mp = np.ascontiguousarray(mode_params, dtype=np.float64)
+        fo = np.ascontiguousarray(frame_offsets, dtype=np.float64)
+        assert mp.ndim == 2 and mp.shape[0] == 4 and fo.shape == (n_frames, 2)
+        self._check(self.lib.vof_texture_stack_dev(self.h, _ptr(out), int(n_frames), _ptr(mp), mp.shape[1], _ptr(fo),
+                                                   float(period), float(scale)), "vof_texture_stack_dev")
 
     def bench_sweeps(self, movie, n_pairs, params, n_sweeps):
         self._check(self.lib.vof_bench_sweeps_dev(self.h, _ptr(movie), n_pairs, C.byref(params), n_sweeps),

@@ -83,6 +83,8 @@ struct vof_ctx {
     hipEvent_t ev_solved[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr}, ev_uploaded[2] = {nullptr, nullptr};
     double* st_movie2 = nullptr;                                 // second frame buffer (upload of the next batch under the solve)
     double *blur_tmp = nullptr, *blur_w = nullptr, *blur_io = nullptr;   // Gaussian blur scratch (lazy)
+    double* tex_tab = nullptr;                                           // synthetic-texture tables (lazy)
+    size_t tex_cap = 0;
     // GMRES fallback (allocated on first use): basis vectors V_0..V_m (each B * len0), per-pair state, partials, flags
     double* gm_V = nullptr;
     GmresState* gm_state = nullptr;
@@ -704,7 +706,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     double sx = P.delta_t / P.delta_x;
     bool zero_guess = (P.initial_v_x == 0.0 && P.initial_v_y == 0.0 && P.initial_remodelling == 0.0);
     if (c->guess_src) {   // warm start from the solution of a neighbouring, already solved pair (cf. OF.py:803-806)
-        { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len); k_gather_guess<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->warm_x, c->guess_src, len); }
+        { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len);
+          k_gather_guess<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->warm_x, c->guess_src, len, f.npts, P.initial_v_x * sx, P.initial_v_y * sx,
+                                                      P.initial_remodelling); }
         residual_d(c, c->kx, c->kb, c->kr, np, nullptr);
     } else if (zero_guess) {
         HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)np * len * sizeof(double), s));
@@ -722,7 +726,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     // krylov_method: 0 = BiCGStab only (the reference's 'bcgs'); 1 = GMRES only; 2 = BiCGStab, and restarted GMRES for
     // the pairs that have not met the tolerance after `fallback_after` iterations (or broke down)
     const int bicg_limit = P.krylov_method == 1 ? 0 : (P.krylov_method == 2 ? std::min(P.max_iterations, P.fallback_after) : P.max_iterations);
-    for (int it = 0; it < bicg_limit; ++it) {
+    int it_total = 0;   // BiCGStab iterations of this batch (all rounds)
+    auto bicg_loop = [&](int limit) -> int {
+    for (int it = 0; it < limit; ++it, ++it_total) {
         HIPCHK(hipMemcpyAsync(c->h_active, c->active, np * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         int nact = 0;
@@ -730,7 +736,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         if (nact == 0) break;
         // vcycle_precision 2 ("auto"): float32 V-cycle vectors for the first iterations, float64 for stragglers
         // (in the slowly converging regimes float32 storage costs iterations)
-        if (P.vcycle_precision == 2 && it == AUTO_F64_AFTER) c->vfloat = false;
+        if (P.vcycle_precision == 2 && it_total == AUTO_F64_AFTER) c->vfloat = false;
         c->cur_units = nact;
         const int* act = c->active;
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
@@ -756,6 +762,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
           VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, (const VT*)c->kz, c->kr, c->kt, c->krh, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
+    return 0;
+    };
+    if (int rc = bicg_loop(bicg_limit)) return rc;
     // independent residual (OF.py:1150-1151): ||b - A x|| recomputed from x for every pair
     auto independent_residual = [&]() -> int {
         c->cur_units = np;
@@ -766,6 +775,23 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         return 0;
     };
     if (int rc = independent_residual()) return rc;
+    // The stopping rule is evaluated on the independent residual.  BiCGStab tests its recursively updated residual, which
+    // drifts from the true one (by rounding; visibly so near the attainable accuracy): pairs it declared converged whose
+    // recomputed residual misses the tolerance are restarted from that residual (r = r^ = b - A x, p = v = 0), which a
+    // further iteration or two settles.  What is still open afterwards goes to GMRES (krylov_method 2).
+    if (bicg_limit > 0) {
+        for (int round = 0; round < 3; ++round) {
+            { Prof p(c, VOF_K_VECTOR, 0); k_bicg_restart<<<(np + 63) / 64, 64, 0, s>>>(c->sc, c->active, np, P.max_iterations); }
+            int nact = count_active(c, np);
+            if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
+            if (nact == 0) break;
+            c->cur_units = nact;
+            { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5);
+              k_restart_vectors<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->krh, c->kp, c->kv, c->kt, len, c->active); }
+            if (int rc = bicg_loop(std::min(bicg_limit, 8))) return rc;
+            if (int rc = independent_residual()) return rc;
+        }
+    }
     if (P.krylov_method != 0) {
         // GMRES takes the pairs BiCGStab left unconverged, and those whose recursively updated residual met the
         // tolerance while the true one does not (the usual drift of BiCGStab at tight tolerances)
@@ -790,7 +816,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
             const PairScalars& q = c->h_sc[k];
             stats[k].iterations = q.iterations;
             stats[k].relative_residual = q.bnorm2 > 0 ? std::sqrt(q.rnorm2 / q.bnorm2) : 0.0;
-            stats[k].converged = (q.converged && !(stats[k].relative_residual > 10 * P.rtol)) ? 1 : 0;
+            stats[k].converged = (q.rnorm2 <= q.tol2) ? 1 : 0;   // the rule on the independent residual (NaN: 0)
             stats[k].L1_functional = c->h_func3[3 * k];
             stats[k].speed_functional = c->h_func3[3 * k + 1];
             stats[k].remodelling_functional = c->h_func3[3 * k + 2];
@@ -801,6 +827,14 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
 
 int check_params(vof_ctx* c, const vof_params* p) {
     if (!p) { c->err = "params is NULL"; return -1; }
+    if (p->struct_size != sizeof(vof_params) || p->abi_version != VOF_VERSION) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "vof_params ABI mismatch: caller has struct_size %u / version %u, library has %zu / %d "
+                 "(fill the struct with vof_default_params(p, sizeof *p) of the matching include/vof.h)",
+                 p->struct_size, p->abi_version, sizeof(vof_params), VOF_VERSION);
+        c->err = buf;
+        return -4;
+    }
     if (!(p->delta_x != 0.0) || !(p->delta_t != 0.0)) { c->err = "delta_x and delta_t must be non-zero"; return -1; }
     if (p->nu_pre < 0 || p->nu_post < 0 || p->nu_pre + p->nu_post == 0) { c->err = "nu_pre + nu_post must be > 0"; return -1; }
     if (p->nu_pre_coarse < 0 || p->nu_post_coarse < 0) { c->err = "nu_*_coarse must be >= 0"; return -1; }
@@ -826,9 +860,13 @@ extern "C" {
 
 int vof_version(void) { return VOF_VERSION; }
 
-void vof_default_params(vof_params* p) {
-    if (!p) return;
+size_t vof_params_size(void) { return sizeof(vof_params); }
+
+int vof_default_params(vof_params* p, size_t struct_size) {
+    if (!p || struct_size != sizeof(vof_params)) return -1;   // a binding built against another layout: write nothing
     memset(p, 0, sizeof *p);
+    p->struct_size = (uint32_t)sizeof(vof_params);
+    p->abi_version = VOF_VERSION;
     p->speed_alpha = 1.0;          // OF.py:718
     p->remodelling_alpha = 1000.0; // OF.py:719
     p->delta_x = 1.0;
@@ -848,6 +886,7 @@ void vof_default_params(vof_params* p) {
     p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
     p->warm_start_stride = 3;      // vof_solve_stack_dev: every 3rd pair first, the others start from their solved neighbour
     p->fallback_after = 25;        // BiCGStab iterations before the fallback (the benchmark regimes need 3-17)
+    return 0;
 }
 
 const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -923,7 +962,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_units, 0, sizeof c->prof_units);
     memset(c->prof_bytes, 0, sizeof c->prof_bytes);
-    vof_default_params(&c->prm);
+    vof_default_params(&c->prm, sizeof c->prm);
     if (const char* e = getenv("VOF_SWEEP_GEO")) {   // experiment switch: "AA", "AB" (default), "BA", "BB" = fine,stored
         c->geo_b_fine = e[0] == 'B';
         c->geo_b_stored = e[0] && e[1] == 'B';
@@ -1011,25 +1050,29 @@ static int solve_stack_two_phase(vof_ctx* c, const double* movie, int P, double*
     std::vector<PairParam> hp((size_t)B);
     std::vector<int> hsrc((size_t)B);
     std::vector<vof_pair_stats> st((size_t)B);
+    std::vector<char> usable((size_t)n1, 0);   // phase-1 solutions that may seed a neighbour: converged and finite
     auto run = [&](const std::vector<int>& list, bool phase2) -> int {
         for (size_t o = 0; o < list.size(); o += (size_t)B) {
             const int np = (int)std::min<size_t>((size_t)B, list.size() - o);
             for (int i = 0; i < np; ++i) {
                 const int k = list[o + i];
                 hp[i] = PairParam{prm.speed_alpha, prm.remodelling_alpha, k, k};
-                hsrc[i] = std::min((k + stride / 2) / stride, n1 - 1);
+                const int src = std::min((k + stride / 2) / stride, n1 - 1);
+                hsrc[i] = usable[src] ? src : -1;   // -1: constant initial fields (a failed pair must not poison its neighbours)
             }
             HIPCHK(hipStreamSynchronize(c->stream));   // the host tables are re-used
             HIPCHK(hipMemcpyAsync(c->pp_buf, hp.data(), (size_t)np * sizeof(PairParam), hipMemcpyHostToDevice, c->stream));
             if (phase2) HIPCHK(hipMemcpyAsync(c->warm_src, hsrc.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice, c->stream));
             c->pp = c->pp_buf;
             c->guess_src = phase2 ? c->warm_src : nullptr;
-            int rc = solve_batch(c, movie, np, v_x, v_y, remodelling, speed, stats ? st.data() : nullptr);
+            int rc = solve_batch(c, movie, np, v_x, v_y, remodelling, speed, st.data());
             c->pp = nullptr;
             c->guess_src = nullptr;
             if (rc) return rc;
-            if (!phase2)
+            if (!phase2) {
                 HIPCHK(hipMemcpyAsync(c->warm_x + o * len, c->kx, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                for (int i = 0; i < np; ++i) usable[o + i] = st[i].converged && std::isfinite(st[i].relative_residual);
+            }
             if (stats)
                 for (int i = 0; i < np; ++i) stats[list[o + i]] = st[i];
         }
@@ -1425,6 +1468,35 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "stream synchronize failed"; return fail(-2); }
     return fail(0);
+}
+
+int vof_texture_stack_dev(vof_ctx* c, double* out, int n_frames, const double* mode_params, int n_modes,
+                          const double* frame_offsets, double period, double scale) {
+    if (!c) return -1;
+    if (!out || !mode_params || !frame_offsets) { c->err = "NULL pointer"; return -1; }
+    if (n_frames < 1 || n_modes < 1 || n_modes > 4096 || !(period > 0.0)) { c->err = "bad n_frames / n_modes / period"; return -1; }
+    HIPCHK(hipSetDevice(c->device));
+    const int width = std::max(c->Ni, c->Nj);
+    const int chunk = std::max(1, std::min(n_frames, (int)(((size_t)64 << 20) / ((size_t)4 * n_modes * width * sizeof(double)))));
+    const size_t need = (size_t)chunk * 4 * n_modes * width + (size_t)4 * n_modes + (size_t)2 * chunk;
+    if (c->tex_cap < need) {
+        if (int rc = dev_alloc(c, &c->tex_tab, need)) return rc;
+        c->tex_cap = need;
+    }
+    double* prm = c->tex_tab + (size_t)chunk * 4 * n_modes * width;
+    double* offs = prm + (size_t)4 * n_modes;
+    HIPCHK(hipMemcpyAsync(prm, mode_params, (size_t)4 * n_modes * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int t0 = 0; t0 < n_frames; t0 += chunk) {
+        const int nf = std::min(chunk, n_frames - t0);
+        HIPCHK(hipMemcpyAsync(offs, frame_offsets + (size_t)2 * t0, (size_t)2 * nf * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        k_texture_tables<<<dim3((width + 255) / 256, n_modes, nf), 256, 0, c->stream>>>(c->tex_tab, width, c->Ni, c->Nj, n_modes, prm,
+                                                                                       offs, period);
+        k_texture_sum<<<dim3((c->Nj + BX - 1) / BX, (c->Ni + BY * TEX_ROWS - 1) / (BY * TEX_ROWS), nf), blk2d, 0, c->stream>>>(
+            c->tex_tab, width, c->Ni, c->Nj, n_modes, scale, out + (size_t)t0 * frame_stride(c));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));   // offs / the tables are re-used by the next chunk; host offsets may be freed
+    }
+    return 0;
 }
 
 int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof_params* p, int n_sweeps) {

@@ -974,9 +974,10 @@ __global__ void k_gm_begin(PairScalars* __restrict__ sc, int* __restrict__ activ
     if (pair >= np) return;
     PairScalars& s = sc[pair];
     // rnorm2 is the independent residual here.  Not converged, or "converged" by the recursive residual while the true
-    // one misses the tolerance by more than 50 % (a marginal miss is not worth allocating the basis for)
-    bool need = !s.converged || s.rnorm2 > 2.25 * s.tol2;
-    int on = (need && s.iterations < max_it && s.bnorm2 > 0.0) ? 1 : 0;
+    // one still misses the tolerance after the BiCGStab restarts
+    bool need = !s.converged || s.rnorm2 > s.tol2;
+    // a non-finite residual (NaN / Inf pixel in the pair's frames) cannot be repaired by more iterations
+    int on = (need && isfinite(s.rnorm2) && s.iterations < max_it && s.bnorm2 > 0.0) ? 1 : 0;
     if (on) { s.converged = 0; s.rho = INFINITY; }   // rho: true residual^2 at the start of the previous cycle
     active[pair] = on;
     cycle[pair] = on;
@@ -1152,12 +1153,49 @@ __global__ void k_gm_solve_y(GmresState* __restrict__ st, const int* __restrict_
 }
 
 // warm start: x[pair] = saved[src[pair]] (interior solution of an already solved neighbouring pair)
+// src[pair] < 0 (the neighbour did not converge or is not finite): the constant initial fields (c0, c1, c2) instead
 __global__ __launch_bounds__(RBLK) void k_gather_guess(double* __restrict__ x, const double* __restrict__ saved,
-                                                       const int* __restrict__ src, size_t len) {
+                                                       const int* __restrict__ src, size_t len, size_t npts, double c0,
+                                                       double c1, double c2) {
     int pair = blockIdx.y;
-    const double* from = saved + (size_t)src[pair] * len;
+    const int sp = src[pair];
     double* to = x + (size_t)pair * len;
+    if (sp < 0) {
+        for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK)
+            to[i] = i < npts ? c0 : (i < 2 * npts ? c1 : c2);
+        return;
+    }
+    const double* from = saved + (size_t)sp * len;
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) to[i] = from[i];
+}
+
+// BiCGStab restart from the true residual: pairs the recursive residual declared converged although the independent
+// residual (rnorm2 after S_FINAL) misses the tolerance.  Scalars as after S_R0 (rho = beta = ||r||^2, alpha = omega = 1).
+__global__ void k_bicg_restart(PairScalars* __restrict__ sc, int* __restrict__ active, int np, int max_it) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= np) return;
+    PairScalars& s = sc[pair];
+    const bool on = s.converged && s.rnorm2 > s.tol2 && isfinite(s.rnorm2) && s.iterations < max_it && !s.breakdown;
+    if (on) {
+        s.converged = 0;
+        s.halfstep = 0;
+        s.alpha = s.omega = 1.0;
+        s.rho = s.beta = s.rnorm2;
+    }
+    active[pair] = on ? 1 : 0;
+}
+// r = r^ = t (the independent residual), p = v = 0 for the restarted pairs
+__global__ __launch_bounds__(RBLK) void k_restart_vectors(double* __restrict__ r, double* __restrict__ rh,
+                                                          double* __restrict__ p, double* __restrict__ v,
+                                                          const double* __restrict__ t, size_t len,
+                                                          const int* __restrict__ active) {
+    int pair = blockIdx.y;
+    if (!active[pair]) return;
+    size_t off = (size_t)pair * len;
+    for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
+        const double a = t[off + i];
+        r[off + i] = a; rh[off + i] = a; p[off + i] = 0.0; v[off + i] = 0.0;
+    }
 }
 
 // x += z (z V-cycle output, float64)
@@ -2029,6 +2067,62 @@ __global__ __launch_bounds__(NT) void k_blur1d(const double* __restrict__ in, do
         acc += (a + b) * w[k + radius];
     }
     out[(size_t)f * Ni * Nj + (size_t)i * Nj + j] = acc;
+}
+
+// ==========================================================================================
+// Synthetic "actin-like" texture of the benchmark configurations (no such generator exists in
+// the reference - harness code, generated on the device so that multi-GiB stacks never cross PCIe):
+//   A_t(i, j) = sum_k a_k cos(2 pi (f_k (i - ox_t) + g_k (j - oy_t)) / N + phi_k),  I_t = clip(0.5 + scale A_t, 0, 1).
+// cos(p + q) = cos p cos q - sin p sin q makes the sum separable: k_texture_tables fills, per frame, the four tables
+// a_k cos p_k(i), a_k sin p_k(i), cos q_k(j), sin q_k(j); k_texture_sum does 2 n_modes FMAs per pixel from them.
+// ==========================================================================================
+// tab layout: [frame][4][n_modes][width], width >= max(Ni, Nj)
+__global__ __launch_bounds__(256) void k_texture_tables(double* __restrict__ tab, int width, int Ni, int Nj, int n_modes,
+                                                        const double* __restrict__ prm /* f, g, a, phi: n_modes each */,
+                                                        const double* __restrict__ offs /* [frame][2] */, double period) {
+    const int t = blockIdx.z, k = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width) return;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double f = prm[k], g = prm[n_modes + k], a = prm[2 * n_modes + k], phi = prm[3 * n_modes + k];
+    const double ox = offs[2 * t], oy = offs[2 * t + 1];
+    double* base = tab + ((size_t)t * 4 * n_modes + k) * width + i;
+    const size_t ms = (size_t)n_modes * width;
+    if (i < Ni) {
+        const double p = two_pi * f * ((double)i - ox) / period + phi;
+        base[0] = a * cos(p);
+        base[ms] = a * sin(p);
+    }
+    if (i < Nj) {
+        const double q = two_pi * g * ((double)i - oy) / period;
+        base[2 * ms] = cos(q);
+        base[3 * ms] = sin(q);
+    }
+}
+
+constexpr int TEX_ROWS = 8;   // rows per thread
+__global__ __launch_bounds__(NT) void k_texture_sum(const double* __restrict__ tab, int width, int Ni, int Nj, int n_modes,
+                                                    double scale, double* __restrict__ out) {
+    const int j = blockIdx.x * BX + threadIdx.x, t = blockIdx.z;
+    const int i0 = (blockIdx.y * BY + threadIdx.y) * TEX_ROWS;
+    if (j >= Nj || i0 >= Ni) return;
+    const size_t ms = (size_t)n_modes * width;
+    const double* T0 = tab + (size_t)t * 4 * ms;
+    double acc[TEX_ROWS];
+#pragma unroll
+    for (int r = 0; r < TEX_ROWS; ++r) acc[r] = 0.0;
+    for (int k = 0; k < n_modes; ++k) {
+        const double cq = T0[2 * ms + (size_t)k * width + j], sq = T0[3 * ms + (size_t)k * width + j];
+        const double* ap = T0 + (size_t)k * width + i0;
+#pragma unroll
+        for (int r = 0; r < TEX_ROWS; ++r) {
+            const int ii = min(i0 + r, Ni - 1) - i0;   // row-uniform (scalar) loads
+            acc[r] += ap[ii] * cq - ap[ms + ii] * sq;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TEX_ROWS; ++r)
+        if (i0 + r < Ni) out[((size_t)t * Ni + i0 + r) * Nj + j] = fmin(fmax(0.5 + scale * acc[r], 0.0), 1.0);
 }
 
 }  // namespace vof

@@ -155,11 +155,11 @@ def _float64_copy(a, n_threads=4):
 def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                    use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
                    multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None, warm_start_stride=None):
-    # krylov_method may be a tuple ("auto", fallback_after): BiCGStab iterations before GMRES takes over
+    """vof_params from the keyword arguments of ``variational_optical_flow``.  ``krylov_method`` may be a tuple
+    ``("auto", fallback_after)``: BiCGStab iterations before GMRES takes over."""
     fallback_after = None
     if isinstance(krylov_method, (tuple, list)):
         krylov_method, fallback_after = krylov_method[0], int(krylov_method[1])
-    """vof_params from the keyword arguments of ``variational_optical_flow``."""
     if rtol is None:
         rtol = 1e-11 if use_direct_solver else 1e-6
     params = _native.default_params(
@@ -242,8 +242,9 @@ def variational_optical_flow(movie,
         ``krylov_method`` ("bicgstab": the reference's KSP type, OF.py:1081; "gmres": restarted GMRES with the same
         preconditioner and stopping rule; "auto" (default): BiCGStab, and GMRES(``gmres_restart``, default 100) for the
         pairs that have not converged after 25 iterations - the grad-div dominated regimes),
-        ``warm_start_stride`` (device-resident mode only: every n-th pair is solved first, the others start from their
-        solved neighbour, cf. OF.py:803-806; default 3, 0 = every pair from the constant initial fields),
+        ``warm_start_stride`` (both modes, stacks whose first phase fills the chip: every n-th pair of a batch is solved
+        first, the others start from their solved neighbour, cf. OF.py:803-806; default 3, 0 = every pair from the
+        constant initial fields),
         ``verbose``, ``return_stats`` (adds ``result['stats']``: per-pair iterations / residual /
         converged / functionals), ``output`` ("numpy": host arrays as in the reference; "torch": ``movie`` may be a
         torch tensor already on the device and every array of the result stays on the device as a float64 torch
@@ -266,7 +267,7 @@ def variational_optical_flow(movie,
         raise ValueError("movie needs at least two frames")
     params = _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                             use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
-                            multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart)
+                            multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart, warm_start_stride)
     exact = max_pairs_in_flight is not None
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
@@ -374,7 +375,8 @@ def vary_regularisation(movie,
     kw = dict(delta_x=1.0, delta_t=1.0, smoothing_sigma=None, initial_v_x=0.0, initial_v_y=0.0, initial_remodelling=0.0,
               use_direct_solver=False, rtol=None, max_iterations=1000, reference_quirks=True, device=0,
               max_pairs_in_flight=None, coarse_precision="float32", vcycle_precision="float64", multigrid_sweeps=None,
-              w_cycle_level=None, krylov_method="auto", gmres_restart=None, verbose=False, return_stats=False)
+              w_cycle_level=None, krylov_method="auto", gmres_restart=None, warm_start_stride=None, verbose=False,
+              return_stats=False)
     for k in kwargs:
         if k not in kw:
             raise TypeError(f"variational_optical_flow() got an unexpected keyword argument {k!r}")
@@ -382,7 +384,8 @@ def vary_regularisation(movie,
     params = _solver_params(1.0, 1.0, kw["delta_x"], kw["delta_t"], kw["initial_v_x"], kw["initial_v_y"],
                             kw["initial_remodelling"], kw["use_direct_solver"], kw["rtol"], kw["max_iterations"],
                             kw["reference_quirks"], kw["coarse_precision"], kw["vcycle_precision"],
-                            kw["multigrid_sweeps"], kw["w_cycle_level"], kw["krylov_method"], kw["gmres_restart"])
+                            kw["multigrid_sweeps"], kw["w_cycle_level"], kw["krylov_method"], kw["gmres_restart"],
+                            kw["warm_start_stride"])       # accepted for signature parity; the sweep batches combinations
     taps = None if kw["smoothing_sigma"] is None else gaussian_taps(kw["smoothing_sigma"])
     # short movies: several combinations share one batch as "virtual pairs" (see vof_vary_regularisation_host)
     n_comb = max(1, len(speed_alpha_values) * len(remodelling_alpha_values))

@@ -35,13 +35,13 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_default_params(lib):
     from opticalflow_amd import _native
-    assert lib.vof_version() == 104
+    assert lib.vof_version() == 200
     p = _native.default_params()
     # the reference's solver settings: OF.py:718-719, 1120
     assert (p.speed_alpha, p.remodelling_alpha, p.rtol, p.max_iterations) == (1.0, 1000.0, 1e-6, 1000)
     assert (p.nu_pre, p.nu_post, p.nu_pre_coarse, p.nu_post_coarse, p.w_cycle_level, p.w_cycle_visits) == (2, 2, 1, 1, 1, 3)
     assert (p.reference_quirks, p.coarse_precision, p.vcycle_precision) == (1, 1, 0)
-    assert C.sizeof(_native.VofParams) == 8 * 8 + 14 * 4
+    assert C.sizeof(_native.VofParams) == 2 * 4 + 8 * 8 + 14 * 4 == lib.vof_params_size()
     assert C.sizeof(_native.VofPairStats) == 40
     with pytest.raises(TypeError):
         _native.default_params(no_such_field=1)
@@ -107,3 +107,41 @@ def test_host_helpers_match_reference_semantics():
     a = np.arange(25.0).reshape(5, 5)
     of.apply_constant_boundary_condition(a)
     assert a[0, 0] == a[2, 2] and a[-1, -1] == a[2, 2] and a[0, 3] == a[2, 3]
+
+
+def test_reference_binding_matches_the_library_and_the_document(lib):
+    """examples/reference_binding.py is the binding INTEGRATION.md prints: same text, same struct layout as the library
+    and as opticalflow_amd/_native.py (field names, order and types), and it refuses another ABI."""
+    import importlib.util
+    from opticalflow_amd import _native
+    path = os.path.join(ROOT, "examples", "reference_binding.py")
+    text = open(path).read()
+    assert text in open(os.path.join(ROOT, "INTEGRATION.md")).read(), "INTEGRATION.md does not print the binding file verbatim"
+    spec = importlib.util.spec_from_file_location("reference_binding", path)
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    assert [(n, t) for n, t in rb.vof_params._fields_] == [(n, t) for n, t in _native.VofParams._fields_]
+    assert [(n, t) for n, t in rb.vof_pair_stats._fields_] == [(n, t) for n, t in _native.VofPairStats._fields_]
+    blib = rb.load(_native.LIB_PATH)
+    assert C.sizeof(rb.vof_params) == blib.vof_params_size() == lib.vof_params_size()
+    assert rb.VOF_VERSION == lib.vof_version()
+    # header <-> binding: every field of struct vof_params in include/vof.h, in order
+    hdr = open(os.path.join(ROOT, "include", "vof.h")).read()
+    body = re.search(r"typedef struct vof_params \{(.*?)\} vof_params;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(?:double|int32_t|uint32_t)\s+([a-z_0-9]+)\s*;", body)
+    assert names == [n for n, _ in rb.vof_params._fields_]
+
+
+def test_abi_guard_rejects_a_stale_struct(lib):
+    """A binding built against a shorter (older) vof_params: vof_default_params writes nothing and says so."""
+    class OldParams(C.Structure):      # the round-1 layout INTEGRATION.md once printed (104 bytes)
+        _fields_ = [(f"d{i}", C.c_double) for i in range(8)] + [(f"i{i}", C.c_int32) for i in range(10)]
+    guard = (C.c_char * 64)()
+    C.memset(guard, 0x5A, 64)
+    old = OldParams()
+    fn = lib.vof_default_params
+    rc = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)(C.cast(fn, C.c_void_p).value)(C.addressof(old), C.sizeof(old))
+    assert rc != 0
+    assert bytes(old) == b"\0" * C.sizeof(old)          # untouched
+    assert bytes(guard) == b"\x5a" * 64

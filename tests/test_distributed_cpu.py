@@ -30,7 +30,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_frames, q):
+def _worker(rank, world, port, n_frames, q, sigma=None, output="numpy"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,22 +46,31 @@ def _worker(rank, world, port, n_frames, q):
             calls.append(sub.shape[0])
             return orc.variational_optical_flow(sub, **kw)
 
-        res = variational_optical_flow_sharded(movie, solve_fn=solve_fn, speed_alpha=1.0, remodelling_alpha=50.0,
-                                               delta_x=0.5, delta_t=1.0)
+        kw = dict(speed_alpha=1.0, remodelling_alpha=50.0, delta_x=0.5, delta_t=1.0)
+        if sigma is not None:
+            kw["smoothing_sigma"] = sigma
+        res = variational_optical_flow_sharded(movie, solve_fn=solve_fn, output=output, **kw)
+        if output == "torch":
+            import torch
+            assert all(isinstance(res[k], torch.Tensor) for k in ("v_x", "v_y", "speed", "remodelling", "original_data",
+                                                                   "blurred_data"))
+            res = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in res.items()}
+        assert (res["blurred_data"] is res["original_data"]) == (sigma is None)      # OF.py:770-773
         q.put((rank, calls, res["v_x"], res["remodelling"], res["L1_functional"], res["speed_functional"],
-               res["converged"]))
+               res["converged"], res["blurred_data"], res["speed"]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [4, 5, 2])
-def test_two_rank_gloo_sharded_solve_matches_single_process(n_frames):
+@pytest.mark.parametrize("n_frames,sigma,output", [(4, None, "numpy"), (5, None, "numpy"), (2, None, "numpy"),
+                                                   (5, 1.5, "numpy"), (4, 1.0, "torch"), (2, 1.5, "numpy")])
+def test_two_rank_gloo_sharded_solve_matches_single_process(n_frames, sigma, output):
     from oracle import vof_oracle as orc
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q, sigma, output)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in range(world)]
@@ -69,9 +78,13 @@ def test_two_rank_gloo_sharded_solve_matches_single_process(n_frames):
         p.join(timeout=60)
         assert p.exitcode == 0
     movie = orc.make_texture_stack(24, n_frames, seed=5)
-    ref = orc.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=50.0, delta_x=0.5, delta_t=1.0)
+    ref = orc.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=50.0, delta_x=0.5, delta_t=1.0,
+                                       **({} if sigma is None else {"smoothing_sigma": sigma}))
     P = n_frames - 1
-    for rank, calls, vx, gm, L1, sf, conv in got:
+    for rank, calls, vx, gm, L1, sf, conv, blurred, speed in got:
+        # the stack the solves ran on (OF.py:1199), re-assembled from the shards' blurred frames
+        np.testing.assert_allclose(blurred, ref["blurred_data"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(speed, ref["speed"], rtol=1e-9, atol=1e-12)
         a, b = shard_pair_range(P, world, rank)
         assert calls == ([b - a + 1] if b > a else [])       # shard + one overlap frame
         assert vx.shape == ref["v_x"].shape
@@ -90,20 +103,27 @@ def _gather_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import torch
-        from opticalflow_amd.distributed import allgather_chunk
-        P, n = 6, 5
-        local = (torch.arange(P * n * n, dtype=torch.float64).reshape(P, n, n) + 1000.0 * rank)
+        from opticalflow_amd.distributed import allgather_chunk, block_cyclic_range, chunk_plan
+        n = 5
+        sizes = [3, 2, 1]                       # uneven chunks, as chunk_plan makes them (small last chunk)
+        P = sum(sizes)
         gathered = torch.full((world * P, n, n), -1.0, dtype=torch.float64)
-        works = [allgather_chunk(gathered, local, a, a + 2, P) for a in (0, 2, 4)]     # 3 chunks, asynchronous
+        works = []
+        for c in range(len(sizes)):
+            g0, g1 = block_cyclic_range(rank, world, sizes, c)
+            # the value of global pair g is g everywhere: the re-assembled stack must come out in natural order
+            local = torch.arange(g0, g1, dtype=torch.float64)[:, None, None].expand(g1 - g0, n, n).contiguous()
+            works.append(allgather_chunk(gathered, local, sizes, c))                   # asynchronous, in place
         for w in works:
             w.wait()
-        q.put((rank, gathered.numpy()))
+        q.put((rank, gathered.numpy(), chunk_plan(128), chunk_plan(255), chunk_plan(40), chunk_plan(9), chunk_plan(9, 3)))
     finally:
         dist.destroy_process_group()
 
 
 def test_chunked_allgather_reassembles_in_natural_order():
-    """bench.py's multi-GPU step: chunk-wise asynchronous all-gathers into the rank-major output stack."""
+    """bench.py's multi-GPU step: pairs dealt block-cyclically, one all_gather_into_tensor per chunk writing its
+    [rank][pair] block of the natural-order stack in place."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -116,9 +136,32 @@ def test_chunked_allgather_reassembles_in_natural_order():
         p.join(timeout=60)
         assert p.exitcode == 0
     P, n = 6, 5
-    expect = np.concatenate([np.arange(P * n * n, dtype=np.float64).reshape(P, n, n) + 1000.0 * r for r in range(world)])
-    for rank, g in got:
+    expect = np.broadcast_to(np.arange(world * P, dtype=np.float64)[:, None, None], (world * P, n, n))
+    for rank, g, p128, p255, p40, p9, p9_3 in got:
         np.testing.assert_array_equal(g, expect)
+        assert p128 == [52, 52, 24] and p255 == [102, 102, 51] and p40 == [20, 20] and p9 == [9] and p9_3 == [3, 3, 3]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts two fresh rank processes itself
+    (distributed.launch_ranks -> torch.distributed.run on 127.0.0.1) and relays rank 0's single line.  The hidden
+    --selftest-launch mode makes the ranks join a gloo group instead of touching a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--selftest-launch"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d == {"selftest": "launch", "n_gpus": 2, "sum": 3.0}
+    # a failing child is not hidden: --gpus 2 under a WORLD_SIZE=1 environment is refused
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
 
 
 def _sweep_worker(rank, world, port, n_sa, n_ra, q):

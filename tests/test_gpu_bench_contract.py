@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "config", "roofline"}
-SMALL = ["--size", "256", "--frames", "10", "--steps", "2", "--warmup", "1", "--no-variants"]
+SMALL = ["--size", "256", "--frames", "10", "--steps", "2", "--warmup", "1", "--no-variants"]   # frames given: same workload at any N
 
 
 def run(cmd):
@@ -42,11 +42,16 @@ def test_single_gpu_line_with_cpu_baseline():
     check(d, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "frame-pairs/s" and c["sample"]
+    assert c["host_cores"] >= 1 and c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0
+    e = d["end_to_end"]
+    assert e["unit"] == "frame-pairs/s" and 0 < e["value"] and e["converged"] is True
+    w = d["roofline"]["whole_solve"]
+    assert 0 < w["frac"] < 1 and w["algorithmic_bytes_per_step"] > 0
     assert d["value"] / c["value"] > 10                # sanity only: the ratio says nothing about kernel quality
 
 
 def test_distributed_launch_line():
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-             "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--no-cpu-baseline"] + SMALL)
+             "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--no-cpu-baseline", "--gather-chunks", "3"] + SMALL)
     check(d, 1)
-    assert d["config"]["allgather"] is True and d["config"]["gather_chunks"] == 3
+    assert d["config"]["allgather"] is True and d["config"]["gather_chunks"] == 3 and d["config"]["chunk_sizes"] == [3, 3, 3]

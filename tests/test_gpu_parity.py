@@ -95,6 +95,17 @@ def test_device_blur_matches_reference(of):
         np.testing.assert_allclose(got, ref, rtol=1e-15, atol=1e-13)
 
 
+def test_device_blur_against_the_real_skimage(of):
+    """The HIP blur against the reference's blur_movie run with the real skimage 0.18.3 (fixture G4b): float64 frames
+    and an 8-bit stack, to 2 ulp."""
+    gb = load_golden("g4b_blur_skimage.npz")
+    np.testing.assert_allclose(of.blur_movie(gb["movie"], float(gb["sigma"])), gb["blurred_skimage"], rtol=0, atol=4.5e-16)
+    for key, sigma in (("blurred_u8_sigma_1p0", 1.0), ("blurred_u8_sigma_2p48", 2.48)):
+        got = of.blur_movie(gb["movie_u8"], sigma)
+        assert got.dtype == np.float64 and got.shape == gb["movie_u8"].shape
+        np.testing.assert_allclose(got, gb[key], rtol=9e-16, atol=0)
+
+
 def test_blur_path(of):
     g = load_golden("g4_blur_64.npz")
     res = of.variational_optical_flow(g["movie"], rtol=1e-10, **golden_kwargs(g))
@@ -429,3 +440,21 @@ def test_seeded_random_medium_sizes_by_independent_residual(of, case):
         rr = np.linalg.norm(b - orc.apply_operator_interior(movie[k], xi, alpha, beta, quirks)) / np.linalg.norm(b)
         assert rr <= 1.6e-8, (k, rr, opts)
         assert rr == pytest.approx(res["stats"]["relative_residual"][k], rel=1e-3)
+
+
+def test_reference_side_binding_runs_on_g1():
+    """examples/reference_binding.py (the stub INTEGRATION.md prints) executed as is: the reference's own experiment
+    AVOF.py:26-50 through vof_solve_stack_host, against the reference-produced fixture G1 at the reference's rtol."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("reference_binding", os.path.join(ROOT, "examples", "reference_binding.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    g = load_golden("g1_avof_simple_50.npz")
+    kw = golden_kwargs(g)
+    out, stats = rb.solve_stack(g["movie"], kw["delta_x"], kw.get("delta_t", 1.0), kw["speed_alpha"], kw["remodelling_alpha"],
+                                kw.get("initial_v_x", 0.0), kw.get("initial_v_y", 0.0), kw.get("initial_remodelling", 0.0))
+    assert all(s.converged for s in stats) and max(s.relative_residual for s in stats) <= 1e-6
+    for arr, key in zip(out[:3], ("v_x", "v_y", "remodelling")):
+        assert relerr(arr, g[key]) < LOOSE, key
+    np.testing.assert_allclose(out[3], np.sqrt(out[0] ** 2 + out[1] ** 2), rtol=1e-14)

@@ -74,6 +74,21 @@ def test_blur_matches_reference():
     np.testing.assert_allclose(orc.blur_movie(g["movie"], 2.0), g["blurred"], rtol=0, atol=1e-15)
 
 
+def test_blur_pinned_on_the_real_skimage():
+    """G4b: the reference's blur_movie (OF.py:282-306) run with the REAL skimage.filters.gaussian (conda python3.9,
+    tests/golden/make_blur_golden.py).  The scipy stand-in that produced G4's blurred stack agrees with it to one ulp
+    (2.2e-16 on [0, 1] data: scipy 1.7 vs 1.15 summation), and so does the oracle; an 8-bit stack as well."""
+    g4, gb = load_golden("g4_blur_64.npz"), load_golden("g4b_blur_skimage.npz")
+    np.testing.assert_array_equal(gb["movie"], g4["movie"])
+    assert tuple(gb["skimage_version"]) == (0, 18, 3)
+    np.testing.assert_allclose(g4["blurred"], gb["blurred_skimage"], rtol=0, atol=2.3e-16)
+    np.testing.assert_allclose(orc.blur_movie(gb["movie"], float(gb["sigma"])), gb["blurred_skimage"], rtol=0, atol=2.3e-16)
+    for key, sigma in (("blurred_u8_sigma_1p0", 1.0), ("blurred_u8_sigma_2p48", 2.48)):
+        got = orc.blur_movie(gb["movie_u8"], sigma)
+        assert got.dtype == np.float64
+        np.testing.assert_allclose(got, gb[key], rtol=9e-16, atol=0)      # 2 ulp
+
+
 def test_fake_frame_generator():
     g = load_golden("g8_fake_frame.npz")
     fr, dx = orc.make_fake_data_frame(1.3, 2.9, sigma=1.7, width=6.0, dimension=37)
