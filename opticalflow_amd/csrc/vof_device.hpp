@@ -1704,6 +1704,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
         // (4) the stage of this wave (row quantities are scalar for the colour waves of GeoA)
         {
             const int rr = e + stage_row_off, p = g.p0 + rr;
+#ifndef SW_EXP_NOCOMPUTE   // experiment build: data movement only
             if (col_ok && rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) {
                 const SweepRows rw = sweep_rows<G>(g, rr, slotA, stage_row_off, (size_t)L.hj, L.sub);
                 double u, w, gm;
@@ -1711,6 +1712,7 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
                 VT* row = xs + rw.pC + cc.cC;
                 row[0] = (VT)u; row[W] = (VT)w; row[2 * W] = (VT)gm;
             }
+#endif
         }
         // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
         if (do_load) {
