@@ -45,7 +45,9 @@ typedef struct vof_params {
     int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction on level 0 (default 2) */
     int32_t nu_post;           /* ... and after (default 2) */
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
-    int32_t coarse_precision;  /* 1 (default): float32 storage of the Galerkin stencils; 0: float64 */
+    int32_t coarse_precision;  /* storage of the Galerkin stencils (preconditioner only): 2 (default) bfloat16 off-diagonal blocks +
+                                  float32 diagonal block that absorbs their rounding errors (block row sums kept; same iteration
+                                  counts as float32, 180 instead of 324 bytes per coarse point); 1: float32; 0: float64 */
     int32_t vcycle_precision;  /* V-cycle vectors: 0 (default) float64; 1 float32 storage; 2 auto = float32 for the first 8
                                   iterations, float64 afterwards (arithmetic, Krylov vectors and stopping rule always FP64) */
     int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
@@ -81,7 +83,7 @@ typedef struct vof_pair_stats {
 enum vof_kernel_id {
     VOF_K_RHS = 0, VOF_K_APPLY0, VOF_K_GS0, VOF_K_GS, VOF_K_RESIDUAL, VOF_K_RESTRICT, VOF_K_PROLONG,
     VOF_K_GALERKIN0, VOF_K_GALERKIN, VOF_K_COARSE_SETUP, VOF_K_COARSE_SOLVE, VOF_K_VECTOR, VOF_K_REDUCE,
-    VOF_K_FINALIZE, VOF_K_FUNCTIONALS, VOF_K_COUNT
+    VOF_K_FINALIZE, VOF_K_FUNCTIONALS, VOF_K_COARSE_TAIL, VOF_K_COUNT
 };
 
 int vof_version(void);
@@ -96,6 +98,8 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *   VOF_STREAM_APPLY=0         level-0 operator: simple kernel instead of the LDS-streaming one
  *   VOF_FUSE_RESTRICT=0        level 0: separate residual and restriction kernels
  *   VOF_FUSE_PROLONG=0         level 0: separate prolongation kernel instead of interpolating inside the first post-sweep
+ *   VOF_SWEEP0=0               level 0: the generic fused sweep kernel instead of the dedicated k_sweep0
+ *   VOF_COARSEST_MAX=3..9      coarsen until max(n_i, n_j) <= this (default 5); changes the hierarchy depth, hence iteration counts
  *   VOF_COARSE_TAIL=0          levels whose whole grid fits one workgroup: one launch per operation instead of the fused
  *                              LDS-resident coarse-tail kernel */
 

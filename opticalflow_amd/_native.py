@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VOF_LIB") or os.path.join(HERE, "csrc", "libvof.so")
 
 K_NAMES = ["rhs", "apply0", "gs0", "gs", "residual", "restrict", "prolong", "galerkin0", "galerkin",
-           "coarse_setup", "coarse_solve", "vector", "reduce", "finalize", "functionals"]
+           "coarse_setup", "coarse_solve", "vector", "reduce", "finalize", "functionals", "coarse_tail"]
 
 
 class VofParams(C.Structure):

@@ -22,7 +22,12 @@ using namespace vof;
 
 namespace {
 
-constexpr int COARSEST_MAX = 9;      // coarsen until max(n_i, n_j) <= 9  (dense inverse of <= 243 unknowns)
+constexpr int COARSEST_MAX = 5;      // coarsen until max(n_i, n_j) <= COARSEST_MAX (5: dense inverse of <= 75 unknowns; was 9 = 243 unknowns, whose
+                                     // Gauss-Jordan inversion took 4.4 ms per batch - the fused coarse-tail kernel makes the extra level free)
+int coarsest_max() {                 // experiment switch VOF_COARSEST_MAX=3..9 (read per call: create and workspace query agree)
+    if (const char* e = getenv("VOF_COARSEST_MAX")) { int v = atoi(e); if (v >= 3 && v <= 9) return v; }
+    return COARSEST_MAX;
+}
 constexpr int MAX_PROF_RECS = 32768;
 constexpr int AUTO_F64_AFTER = 8;   // vcycle_precision == 2: switch the V-cycle vectors to float64 after this many iterations
 
@@ -99,12 +104,19 @@ struct vof_ctx {
     const double* frames = nullptr;  // device pointer to frame 0 of the current batch
     int npairs = 0;
     vof_params prm;
-    bool hierarchy_float = false;
+    int cfmt = 0;   // storage format of the stored stencils of the current hierarchy: 0 double, 1 float, 2 CoefB16 (levels >= 1;
+                    // the stored level 0 of a one-level grid is always double)
     bool fused = true;   // fused streaming 4-colour sweeps (false: one launch per colour)
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
     bool fuse_prolong = true;   // level 0: coarse-grid correction interpolated inside the first post-sweep
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
+    bool sweep0 = true;         // level 0: dedicated k_sweep0 kernel (VOF_SWEEP0=0: the generic k_sweep<SweepFine, GeoA>)
+    bool tail_enabled = true;   // fused LDS-resident coarse-tail kernel (VOF_COARSE_TAIL=0: one launch per operation)
+    int tail_first = -1;        // first level of the tail (-1: no tail for this grid)
+    size_t tail_lds = 0;        // dynamic LDS bytes of k_tail_cycle
+    TailArgs tail;              // levels / LDS layout; the operation list is rebuilt when the cycle parameters change
+    int tail_key[6] = {-9, -9, -9, -9, -9, -9};   // cycle parameters the operation list was built for
     // profiler
     bool prof = false;
     int prof_kid = -1, prof_level = -1;  // filter (-1 = any)
@@ -207,21 +219,27 @@ inline size_t frame_stride(const vof_ctx* c) { return (size_t)c->Ni * c->Nj; }
         else { using VT = double; __VA_ARGS__; }            \
     } while (0)
 
+// CT = storage format of the stored stencil of level l (word type CW)
+#define CDISPATCH(c, l, ...)                                                                        \
+    do {                                                                                            \
+        const int cf_ = ((l) > 0) ? (c)->cfmt : 0;                                                  \
+        if (cf_ == 2) { using CT = CoefB16; using CW = uint32_t; __VA_ARGS__; }                     \
+        else if (cf_ == 1) { using CT = float; using CW = float; __VA_ARGS__; }                     \
+        else { using CT = double; using CW = double; __VA_ARGS__; }                                 \
+    } while (0)
+inline double coef_bytes(const vof_ctx* c, int l) { const int f = l > 0 ? c->cfmt : 0; return f == 2 ? 45.0 * 4 : (f == 1 ? 81.0 * 4 : 81.0 * 8); }
+
 // one colour, in place, one launch per colour: the simple reference smoother (double vectors only)
 void gs_colour(vof_ctx* c, int l, double* x, const double* b, int colour, int np, const int* active) {
     Level& lv = c->L[l];
     dim3 g = grid2d_colour(lv.ni, lv.nj, colour, np);
-    const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
     if (l == 0 && c->L.size() > 1) {
         Prof p(c, VOF_K_GS0, 0, 20.0 * lv.npts);
         k_gs0<<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, c->prm.speed_alpha,
                                           c->prm.remodelling_alpha, c->prm.reference_quirks, x, b, colour, active, c->pp);
     } else {
-        Prof p(c, VOF_K_GS, l, (81.0 * cb + 72.0) / 4.0 * lv.npts);
-        if (c->hierarchy_float && l > 0)
-            k_gs<float><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, colour, active);
-        else
-            k_gs<double><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, colour, active);
+        Prof p(c, VOF_K_GS, l, (coef_bytes(c, l) + 72.0) / 4.0 * lv.npts);
+        CDISPATCH(c, l, (k_gs<CT><<<g, blk2d, 0, c->stream>>>((const CW*)lv.C, lv.ni, lv.nj, x, b, colour, active)));
     }
 }
 
@@ -288,15 +306,9 @@ template <typename VT>
 void apply_stored_t(vof_ctx* c, int l, const VT* x, const VT* b, VT* y, int mode, int np, const int* active) {
     Level& lv = c->L[l];
     dim3 g = grid2d(lv.ni, lv.nj, np);
-    bool f = c->hierarchy_float && l > 0;
-    Prof p(c, VOF_K_RESIDUAL, l, (81.0 * (f ? 4.0 : 8.0) + (mode ? 9.0 : 6.0) * sizeof(VT)) * lv.npts);
-    if (f) {
-        if (mode) k_apply<float, 1, VT><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
-        else k_apply<float, 0, VT><<<g, blk2d, 0, c->stream>>>((const float*)lv.C, lv.ni, lv.nj, x, b, y, active);
-    } else {
-        if (mode) k_apply<double, 1, VT><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
-        else k_apply<double, 0, VT><<<g, blk2d, 0, c->stream>>>((const double*)lv.C, lv.ni, lv.nj, x, b, y, active);
-    }
+    Prof p(c, VOF_K_RESIDUAL, l, (coef_bytes(c, l) + (mode ? 9.0 : 6.0) * sizeof(VT)) * lv.npts);
+    if (mode) CDISPATCH(c, l, (k_apply<CT, 1, VT><<<g, blk2d, 0, c->stream>>>((const CW*)lv.C, lv.ni, lv.nj, x, b, y, active)));
+    else CDISPATCH(c, l, (k_apply<CT, 0, VT><<<g, blk2d, 0, c->stream>>>((const CW*)lv.C, lv.ni, lv.nj, x, b, y, active)));
 }
 
 // V-cycle internal operator application on level l (all vectors VT)
@@ -382,20 +394,21 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double) +
                      (ecoarse ? (size_t)(3 * 3 * (W / 2 + 2)) * sizeof(VT) : 0);
         if (geoB) k_sweep<SweepFine, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+        else if (c->sweep0) {   // the dedicated level-0 kernel (same geometry, schedule and bits as k_sweep<SweepFine, GeoA>)
+            Fine0 f0{pol.frames, pol.frame_stride, pol.Nj, pol.alpha, pol.beta, pol.quirks, pol.pp};
+            if (ecoarse) k_sweep0<VT, true, false><<<g, S0_THREADS, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+            else if (!x_in) k_sweep0<VT, false, true><<<g, S0_THREADS, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+            else k_sweep0<VT, false, false><<<g, S0_THREADS, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+        }
         else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
     } else {
-        const double cb = (c->hierarchy_float && l > 0) ? 4.0 : 8.0;
-        Prof p(c, VOF_K_GS, l, (81.0 * cb + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C(81) + b(3) + x(3) in, x(3) out
+        Prof p(c, VOF_K_GS, l, (coef_bytes(c, l) + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
-        if (c->hierarchy_float && l > 0) {
-            SweepStored<float> pol; pol.C = (const float*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
-            if (geoB) k_sweep<SweepStored<float>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
-            else k_sweep<SweepStored<float>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
-        } else {
-            SweepStored<double> pol; pol.C = (const double*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
-            if (geoB) k_sweep<SweepStored<double>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
-            else k_sweep<SweepStored<double>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
-        }
+        CDISPATCH(c, l, {
+            SweepStored<CT> pol; pol.C = (const CW*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
+            if (geoB) k_sweep<SweepStored<CT>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+            else k_sweep<SweepStored<CT>, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+        });
     }
 }
 
@@ -440,6 +453,53 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
     return x;
 }
 
+// ---- coarse tail (k_tail_cycle): levels tail_first .. last in one launch, one workgroup per pair
+void tail_emit(const vof_ctx* c, std::vector<unsigned char>* ops, int l, bool from_zero) {
+    const vof_params& P = c->prm;
+    const int last = (int)c->L.size() - 1, tl = l - c->tail_first;
+    auto emit = [&](int code, int arg) { ops[0].push_back((unsigned char)code); ops[1].push_back((unsigned char)tl); ops[2].push_back((unsigned char)arg); };
+    if (l == last) { emit(T_COARSE, 0); return; }
+    const int nu1 = P.nu_pre_coarse > 0 ? P.nu_pre_coarse : P.nu_pre;
+    const int nu2 = P.nu_post_coarse > 0 ? P.nu_post_coarse : P.nu_post;
+    emit(T_SMOOTH, (nu1 << 2) | (from_zero ? 1 : 0));
+    emit(T_RESTRICT, 0);
+    tail_emit(c, ops, l + 1, true);
+    if (P.w_cycle_level == l && l + 1 < last) {
+        const int visits = P.w_cycle_visits > 0 ? P.w_cycle_visits : 2;
+        for (int v = 1; v < visits; ++v) tail_emit(c, ops, l + 1, false);
+    }
+    emit(T_PROLONG, 0);
+    emit(T_SMOOTH, (nu2 << 2) | 2);
+}
+
+// (Re)build the operation list for the current cycle parameters; false: the tail cannot be used (too many operations)
+bool tail_prepare(vof_ctx* c) {
+    if (c->tail_first < 0 || !c->tail_enabled || !c->fused) return false;
+    const vof_params& P = c->prm;
+    const int key[6] = {P.nu_pre, P.nu_post, P.nu_pre_coarse, P.nu_post_coarse, P.w_cycle_level, P.w_cycle_visits};
+    if (memcmp(key, c->tail_key, sizeof key) != 0) {
+        std::vector<unsigned char> ops[3];
+        tail_emit(c, ops, c->tail_first, true);
+        memcpy(c->tail_key, key, sizeof key);
+        if (ops[0].size() > (size_t)TAIL_MAX_OPS - 1 || std::max({P.nu_pre, P.nu_post, P.nu_pre_coarse, P.nu_post_coarse}) > 63) { c->tail.n_ops = -1; return false; }
+        c->tail.n_ops = (int)ops[0].size();
+        for (int i = 0; i < c->tail.n_ops; ++i) { c->tail.op[i] = ops[0][i]; c->tail.op_level[i] = ops[1][i]; c->tail.op_arg[i] = ops[2][i]; }
+    }
+    return c->tail.n_ops > 0;
+}
+
+template <typename VT>
+void tail_cycle_t(vof_ctx* c, VT* x, const VT* b, int np, const int* active, bool from_zero) {
+    TailArgs A = c->tail;
+    const int l0 = c->tail_first, last = (int)c->L.size() - 1;
+    for (int l = l0; l <= last; ++l) A.L[l - l0].C = c->L[l].C;
+    A.invT = c->invT;
+    if (!from_zero) A.op_arg[0] &= ~1;   // the first operation is the pre-smoothing of the top tail level
+    const Level& top = c->L[l0];
+    Prof p(c, VOF_K_COARSE_TAIL, l0, (from_zero ? 6.0 : 9.0) * sizeof(VT) * top.npts);   // b in, x (in and) out; stencils stay in cache
+    CDISPATCH(c, l0, (k_tail_cycle<CT, VT><<<np, TAIL_THREADS, c->tail_lds, c->stream>>>(A, b, x, from_zero ? 1 : 0, active)));
+}
+
 // One multigrid cycle on level l for A_l x = b, starting from a zero guess (from_zero) or from the contents of x.
 // (x, tmp) are the level's ping-pong buffers.  Returns the buffer holding the result: `x`, or - on the levels >= 1,
 // where the caller only reads it - `tmp`.  With prm.w_cycle_level == l the next coarser level is visited twice
@@ -448,6 +508,7 @@ template <typename VT>
 VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* active, bool from_zero = true) {
     int last = (int)c->L.size() - 1;
     if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return x; }
+    if (l == c->tail_first && l > 0 && tail_prepare(c)) { tail_cycle_t<VT>(c, x, b, np, active, from_zero); return x; }
     Level& lv = c->L[l];
     Level& nx = c->L[l + 1];
     const int nu1 = (l > 0 && c->prm.nu_pre_coarse > 0) ? c->prm.nu_pre_coarse : c->prm.nu_pre;
@@ -480,29 +541,20 @@ void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
 // Build the Galerkin hierarchy and the coarsest-level dense inverse for the current batch.
 int build_hierarchy(vof_ctx* c, int np) {
     const vof_params& P = c->prm;
-    c->hierarchy_float = P.coarse_precision == 1;
+    c->cfmt = P.coarse_precision;
     int nl = (int)c->L.size();
     for (int l = 0; l + 1 < nl; ++l) {
         Level &f = c->L[l], &k = c->L[l + 1];
         dim3 g = grid2d(k.ni, k.nj, np);
         if (l == 0) {
             Prof p(c, VOF_K_GALERKIN0, 0);
-            if (c->hierarchy_float)
-                k_galerkin<double, float, true><<<g, blk2d, 0, c->stream>>>(
-                    c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
-                    nullptr, f.ni, f.nj, (float*)k.C, k.ni, k.nj, c->pp);
-            else
-                k_galerkin<double, double, true><<<g, blk2d, 0, c->stream>>>(
-                    c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
-                    nullptr, f.ni, f.nj, (double*)k.C, k.ni, k.nj, c->pp);
+            CDISPATCH(c, 1, (k_galerkin<double, CT, true><<<g, blk2d, 0, c->stream>>>(
+                                 c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
+                                 nullptr, f.ni, f.nj, (CW*)k.C, k.ni, k.nj, c->pp)));
         } else {
             Prof p(c, VOF_K_GALERKIN, l);
-            if (c->hierarchy_float)
-                k_galerkin<float, float, false><<<g, blk2d, 0, c->stream>>>(
-                    nullptr, 0, 0, 0.0, 0.0, 0, (const float*)f.C, f.ni, f.nj, (float*)k.C, k.ni, k.nj, nullptr);
-            else
-                k_galerkin<double, double, false><<<g, blk2d, 0, c->stream>>>(
-                    nullptr, 0, 0, 0.0, 0.0, 0, (const double*)f.C, f.ni, f.nj, (double*)k.C, k.ni, k.nj, nullptr);
+            CDISPATCH(c, 1, (k_galerkin<CT, CT, false><<<g, blk2d, 0, c->stream>>>(
+                                 nullptr, 0, 0, 0.0, 0.0, 0, (const CW*)f.C, f.ni, f.nj, (CW*)k.C, k.ni, k.nj, nullptr)));
         }
     }
     return 0;
@@ -553,17 +605,14 @@ int setup_batch(vof_ctx* c, const double* frames_dev, int np) {
         k_store_fine_stencil<<<grid2d(f.ni, f.nj, np), blk2d, 0, c->stream>>>(
             c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha,
             c->prm.reference_quirks, f.ni, f.nj, (double*)f.C, c->pp);
-        c->hierarchy_float = false;
+        c->cfmt = 0;
     } else {
         build_hierarchy(c, np);
     }
     Level& last = c->L[nl - 1];
     {
         Prof p(c, VOF_K_COARSE_SETUP, nl - 1);
-        if (c->hierarchy_float && nl > 1)
-            k_coarse_build<float><<<np, 256, 0, c->stream>>>((const float*)last.C, last.ni, last.nj, c->W);
-        else
-            k_coarse_build<double><<<np, 256, 0, c->stream>>>((const double*)last.C, last.ni, last.nj, c->W);
+        CDISPATCH(c, nl - 1, (k_coarse_build<CT><<<np, 256, 0, c->stream>>>((const CW*)last.C, last.ni, last.nj, c->W)));
         k_coarse_invert<<<np, 1024, 0, c->stream>>>(c->W, c->nd, c->invT);
     }
     HIPCHK(hipGetLastError());
@@ -841,7 +890,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->w_cycle_level < -1 || p->w_cycle_level > 15) { c->err = "w_cycle_level must be -1 or a level index"; return -1; }
     if (p->w_cycle_visits < 0 || p->w_cycle_visits > 8) { c->err = "w_cycle_visits must be in [0, 8]"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
-    if (p->coarse_precision != 0 && p->coarse_precision != 1) { c->err = "coarse_precision must be 0 or 1"; return -1; }
+    if (p->coarse_precision < 0 || p->coarse_precision > 2) { c->err = "coarse_precision must be 0, 1 or 2"; return -1; }
     if (p->vcycle_precision < 0 || p->vcycle_precision > 2) { c->err = "vcycle_precision must be 0, 1 or 2"; return -1; }
     if (p->krylov_method < 0 || p->krylov_method > 2) { c->err = "krylov_method must be 0, 1 or 2"; return -1; }
     if (p->gmres_restart < 0 || p->gmres_restart > GM_MAXM) { c->err = "gmres_restart must be in [0, 128]"; return -1; }
@@ -880,7 +929,8 @@ int vof_default_params(vof_params* p, size_t struct_size) {
     p->w_cycle_level = 1;          // level 1 visits level 2 several times per cycle (one-level W-cycle) ...
     p->w_cycle_visits = 3;         // ... three times: 5.35 -> 3.4 BiCGStab iterations on the benchmark workload
     p->reference_quirks = 1;
-    p->coarse_precision = 1;       // float32 storage of the Galerkin stencils (preconditioner only)
+    p->coarse_precision = 2;       // Galerkin stencils (preconditioner only): bfloat16 off-diagonal blocks, float32 diagonal
+                                   // block that keeps the block row sums - same iteration counts as float32 in every regime
     p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)
     p->krylov_method = 2;          // BiCGStab (the reference's 'bcgs'); stragglers are finished by restarted GMRES
     p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
@@ -897,7 +947,7 @@ size_t vof_query_workspace(int n_i, int n_j, int B) {
     if (n_i < 4 || n_j < 4 || B < 1) return 0;
     size_t ni = n_i - 2, nj = n_j - 2, total = 0, b = (size_t)B;
     std::vector<std::pair<size_t, size_t>> lv{{ni, nj}};
-    while (std::max(lv.back().first, lv.back().second) > (size_t)COARSEST_MAX)
+    while (std::max(lv.back().first, lv.back().second) > (size_t)coarsest_max())
         lv.push_back({(lv.back().first + 1) / 2, (lv.back().second + 1) / 2});
     total += 10 * b * 3 * ni * nj;
     for (size_t l = 0; l < lv.size(); ++l) {
@@ -923,7 +973,7 @@ int vof_device_memory(int device_id, size_t* free_bytes, size_t* total_bytes) {
 const char* vof_kernel_name(int k) {
     static const char* names[VOF_K_COUNT] = {"rhs", "apply0", "gs0", "gs", "residual", "restrict", "prolong",
                                              "galerkin0", "galerkin", "coarse_setup", "coarse_solve", "vector",
-                                             "reduce", "finalize", "functionals"};
+                                             "reduce", "finalize", "functionals", "coarse_tail"};
     return (k >= 0 && k < VOF_K_COUNT) ? names[k] : "?";
 }
 
@@ -970,10 +1020,12 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_STREAM_APPLY")) c->stream_apply = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_RESTRICT")) c->fuse_restrict = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
+    if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
+    if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
     c->L.push_back(l0);
-    while (std::max(c->L.back().ni, c->L.back().nj) > COARSEST_MAX) {
+    while (std::max(c->L.back().ni, c->L.back().nj) > coarsest_max()) {
         Level k; k.ni = (c->L.back().ni + 1) / 2; k.nj = (c->L.back().nj + 1) / 2; k.npts = (size_t)k.ni * k.nj;
         c->L.push_back(k);
     }
@@ -998,6 +1050,40 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
         }
     }
     c->nd = 3 * (int)c->L.back().npts;
+    {   // coarse tail: the deepest run of levels that fit one workgroup (and its LDS)
+        int first = -1;
+        for (int l = 1; l < nl; ++l) {
+            const CLay lay(c->L[l].ni, c->L[l].nj);
+            if (c->L[l].npts <= (size_t)TAIL_MAX_PTS && lay.sub <= (size_t)TAIL_MAX_SUB) { first = l; break; }
+        }
+        if (first >= 0) first = std::max(first, nl - TAIL_MAX_LEVELS);
+        if (first >= 1 && first < nl - 1) {
+            memset(&c->tail, 0, sizeof c->tail);
+            int off = 0;
+            for (int l = first; l < nl; ++l) {
+                TailLevel& t = c->tail.L[l - first];
+                const CLay lay(c->L[l].ni, c->L[l].nj);
+                t.ni = c->L[l].ni; t.nj = c->L[l].nj; t.hj = lay.hj; t.sub = (int)lay.sub; t.plane = lay.plane;
+                t.xo = off; off += 3 * (t.ni + 2) * (t.nj + 2);
+                t.bo = off; off += 3 * t.ni * t.nj;
+            }
+            c->tail.ro = off; off += 3 * (int)c->L[first].npts;
+            c->tail.nl = nl - first;
+            c->tail.nd = c->nd;
+            c->tail.n_ops = 0;
+            c->tail_lds = (size_t)off * sizeof(double);
+            if (c->tail_lds <= (size_t)150 * 1024) {
+                c->tail_first = first;
+                const int lds = (int)c->tail_lds;
+                HIPCHK(hipFuncSetAttribute((const void*)k_tail_cycle<CoefB16, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(hipFuncSetAttribute((const void*)k_tail_cycle<CoefB16, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(hipFuncSetAttribute((const void*)k_tail_cycle<float, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(hipFuncSetAttribute((const void*)k_tail_cycle<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(hipFuncSetAttribute((const void*)k_tail_cycle<double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIPCHK(hipFuncSetAttribute((const void*)k_tail_cycle<double, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            }
+        }
+    }
     if (int rc = dev_alloc(c, &c->W, (size_t)B * c->nd * 2 * c->nd)) return rc;
     if (int rc = dev_alloc(c, &c->invT, (size_t)B * c->nd * c->nd)) return rc;
     c->nblk = (int)std::min<size_t>(256, std::max<size_t>(1, (len0 + 4 * RBLK - 1) / (4 * RBLK)));
@@ -1723,22 +1809,42 @@ int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
     DBG_LEVEL(level)
     if (!lv.C) { c->err = "level has no stored stencil"; return -1; }
     const CLay L(lv.ni, lv.nj);
-    size_t n = (size_t)c->npairs * 81 * L.plane;
-    std::vector<double> tmp(n);
-    if (c->hierarchy_float && level > 0) {
+    const int fmt = level > 0 ? c->cfmt : 0;
+    const int planes = fmt == 2 ? 45 : 81;
+    const size_t n = (size_t)c->npairs * planes * L.plane;
+    // colour-split device layout -> row-major [pair][81][n_i][n_j]
+    auto unpack = [&](auto get) {
+        for (int k = 0; k < c->npairs; ++k)
+            for (int pl = 0; pl < 81; ++pl)
+                for (int p = 0; p < lv.ni; ++p)
+                    for (int q = 0; q < lv.nj; ++q)
+                        c_host[((size_t)k * 81 + pl) * lv.npts + (size_t)p * lv.nj + q] = get((size_t)k * planes * L.plane, pl, L.idx(p, q));
+    };
+    if (fmt == 2) {   // 36 planes of packed bfloat16 pairs (off-diagonal blocks) + 9 float32 planes (diagonal block)
+        std::vector<uint32_t> tw(n);
+        HIPCHK(hipMemcpy(tw.data(), lv.C, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        unpack([&](size_t base, int pl, size_t idx) -> double {
+            const int d = pl / 9, e = pl % 9;
+            uint32_t bits;
+            if (d == 4) bits = tw[base + (size_t)(36 + e) * L.plane + idx];
+            else {
+                const int j = (d < 4 ? d : d - 1) * 9 + e;
+                const uint32_t v = tw[base + (size_t)(j >> 1) * L.plane + idx];
+                bits = (j & 1) ? (v & 0xFFFF0000u) : (v << 16);
+            }
+            float f;
+            memcpy(&f, &bits, 4);
+            return f;
+        });
+    } else if (fmt == 1) {
         std::vector<float> tf(n);
         HIPCHK(hipMemcpy(tf.data(), lv.C, n * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) tmp[i] = tf[i];
+        unpack([&](size_t base, int pl, size_t idx) -> double { return tf[base + (size_t)pl * L.plane + idx]; });
     } else {
+        std::vector<double> tmp(n);
         HIPCHK(hipMemcpy(tmp.data(), lv.C, n * sizeof(double), hipMemcpyDeviceToHost));
+        unpack([&](size_t base, int pl, size_t idx) -> double { return tmp[base + (size_t)pl * L.plane + idx]; });
     }
-    // colour-split device layout -> row-major [pair][81][n_i][n_j]
-    for (int k = 0; k < c->npairs; ++k)
-        for (int pl = 0; pl < 81; ++pl)
-            for (int p = 0; p < lv.ni; ++p)
-                for (int q = 0; q < lv.nj; ++q)
-                    c_host[((size_t)k * 81 + pl) * lv.npts + (size_t)p * lv.nj + q] =
-                        tmp[((size_t)k * 81 + pl) * L.plane + L.idx(p, q)];
     return 0;
 }
 

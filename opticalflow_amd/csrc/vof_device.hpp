@@ -68,6 +68,69 @@ struct CLay {
 };
 
 // ------------------------------------------------------------------------------------------
+// Storage formats of a stored 9-point block stencil: 81 coefficients per point, index i = d * 9 + e with d = neighbour
+// (a * 3 + b, a/b = row/column offset + 1) and e = 3 * (row of the 3x3 block) + column.
+//   double / float : 81 planes of that type.
+//   CoefB16        : 45 planes of 32-bit words.  The 72 off-diagonal coefficients are bfloat16 (the upper half of the
+//                    float32 bit pattern, round to nearest even), two per word (coefficient j of the off-diagonal list in
+//                    bits 16 (j & 1) ..; the list skips d = 4); the diagonal block (d = 4) stays float32 in planes 36-44
+//                    and ABSORBS the rounding errors of the other blocks, so that every block row sum
+//                    sum_d A(d) is the float32 one.  Measured (scripts/gpu_regimes3.py, VOF_EXP_QUANT): plain rounding of
+//                    the coefficients to 11 bits costs 30-100 % more iterations where beta >> alpha (the gamma rows are
+//                    "-1 - 4 beta, beta, beta, beta, beta": the screening term -1 IS the row sum and drowns in the
+//                    rounding of the betas), whereas with the row sums kept even 8 bits (bfloat16) leave every
+//                    iteration count of every regime unchanged.  180 instead of 324 bytes per point.
+// ------------------------------------------------------------------------------------------
+struct CoefB16 {};
+template <typename CT> struct CoefFmt { typedef CT word_t; static constexpr int PLANES = 81; };
+template <> struct CoefFmt<CoefB16> { typedef uint32_t word_t; static constexpr int PLANES = 45; };
+
+__device__ __forceinline__ uint32_t bf16_round(float f) {   // bfloat16 bits (in the low half) of f, round to nearest even
+    uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// The coefficients of one point in registers.
+template <typename CT> struct CoefSet {
+    typedef typename CoefFmt<CT>::word_t word_t;
+    static constexpr int PLANES = CoefFmt<CT>::PLANES;
+    word_t w[PLANES];
+    __device__ __forceinline__ void load(const word_t* __restrict__ sp, size_t plane) {
+#pragma unroll
+        for (int k = 0; k < PLANES; ++k) w[k] = sp[(size_t)k * plane];
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < PLANES; ++k) w[k] = 0;
+    }
+    // coefficient i = d * 9 + e (a compile-time constant once the caller's loops are unrolled)
+    __device__ __forceinline__ double get(int i) const {
+        if constexpr (std::is_same<CT, CoefB16>::value) {
+            const int d = i / 9, e = i - 9 * d;
+            if (d == 4) return (double)__uint_as_float(w[36 + e]);
+            const int j = (d < 4 ? d : d - 1) * 9 + e;
+            const uint32_t v = w[j >> 1];
+            return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+        } else {
+            return (double)w[i];
+        }
+    }
+};
+// one coefficient with a run-time index (set-up code only)
+template <typename CT>
+__device__ __forceinline__ double coef_at(const typename CoefFmt<CT>::word_t* __restrict__ Cp, size_t plane, size_t idx, int i) {
+    if constexpr (std::is_same<CT, CoefB16>::value) {
+        const int d = i / 9, e = i - 9 * d;
+        if (d == 4) return (double)__uint_as_float(Cp[(size_t)(36 + e) * plane + idx]);
+        const int j = (d < 4 ? d : d - 1) * 9 + e;
+        const uint32_t v = Cp[(size_t)(j >> 1) * plane + idx];
+        return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+    } else {
+        return (double)Cp[(size_t)i * plane + idx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Image-derived coefficients of one interior pixel (OF.py:812-827).
 // ------------------------------------------------------------------------------------------
 struct PixCoef {
@@ -187,6 +250,59 @@ __device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double 
 }
 
 // ------------------------------------------------------------------------------------------
+// Block Gauss-Seidel update of one level-0 point, shared by the per-colour kernel k_gs0 and the fused streaming sweep
+// k_sweep0 (same operations in the same order: the two are bit-identical, which the tests rely on).
+// im[9]: the 3x3 image neighbourhood (index (di+1)*3 + (dj+1)); n: neighbour unknowns with the ghosts already folded
+// onto their mirror points, corner ghosts still WITHOUT their factor 2 - CORNERS applies it (s?? = 2 at the four
+// corner pixels of the image, else 1; multiplying by 1 or 2 is exact, so both variants give the same bits elsewhere).
+// The 2x2 determinant is inverted with v_rcp_f64 + two Newton steps (relative error < 1e-15) instead of an IEEE
+// division, and the division by the constant -1 - 4 beta is a multiplication by its reciprocal `inv_g`: a smoother
+// needs neither to be correctly rounded, and the two divisions were a quarter of the update's instructions.
+// ------------------------------------------------------------------------------------------
+template <bool CORNERS>
+__device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
+                                          double alpha, double beta, double inv_g, int quirks, double b0, double b1,
+                                          double b2, double& u, double& w, double& gm) {
+    // Every fused multiply-add is written out and automatic contraction is off: the compiler's own fusion choices depend
+    // on the surrounding code, and the per-colour kernel and the streaming kernel must round identically.
+#pragma clang fp contract(off)
+    const double P = im[4];
+    const double Dx = (im[7] - im[1]) * 0.5;                          // OF.py:696-697
+    const double Dy = quirks ? Dx : (im[5] - im[3]) * 0.5;            // OF.py:698-699 ('dy' returns the x-derivative)
+    const double Dxx = fma(-2.0, P, im[7] + im[1]);                   // OF.py:702-703
+    const double Dyy = fma(-2.0, P, im[5] + im[3]);                   // OF.py:704-705
+    const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;        // OF.py:700-701
+    const double PP = P * P, PDx = P * Dx, PDy = P * Dy, hP = 0.5 * P;
+    const double A1 = PP + alpha, qPP = 0.25 * PP, hPDx = 0.5 * PDx, hPDy = 0.5 * PDy;
+    const double du71 = n.u[7] - n.u[1], du53 = n.u[5] - n.u[3], dw71 = n.w[7] - n.w[1], dw53 = n.w[5] - n.w[3];
+    double W4, U4;
+    if (CORNERS) {   // products with 1 or 2 are exact: same bits as the plain sums wherever no corner ghost is involved
+        W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
+        U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+    } else {
+        W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
+        U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+    }
+    // off-diagonal part of A x (OF.py:843-960 with the ghost couplings folded), two partial sums per row
+    const double y0a = fma(hPDx, dw53, fma(alpha, n.u[3] + n.u[5], A1 * (n.u[1] + n.u[7])));
+    const double y0b = fma(hP, n.g[1] - n.g[7], fma(qPP, W4, fma(hPDy, dw71, PDx * du71)));
+    const double y1a = fma(hPDy, du71, fma(alpha, n.w[1] + n.w[7], A1 * (n.w[3] + n.w[5])));
+    const double y1b = fma(hP, n.g[3] - n.g[5], fma(qPP, U4, fma(hPDx, du53, PDy * dw53)));
+    const double y2 = fma(hP, du71 + dw53, beta * ((n.g[1] + n.g[7]) + (n.g[3] + n.g[5])));
+    const double r0 = b0 - (y0a + y0b), r1 = b1 - (y1a + y1b), r2 = b2 - y2;
+    // diagonal block [[axx, c, 0], [c, ayy, 0], [Dx, Dy, -1 - 4 beta]]: 2x2 solve, then back-substitution
+    const double m4a = -4.0 * alpha;
+    const double axx = fma(P, fma(-2.0, P, Dxx), m4a), ayy = fma(P, fma(-2.0, P, Dyy), m4a), c = P * Dxy;
+    const double det = fma(axx, ayy, -(c * c));
+    double inv = __builtin_amdgcn_rcp(det);                            // v_rcp_f64 + two Newton steps
+    inv = fma(fma(-det, inv, 1.0), inv, inv);
+    inv = fma(fma(-det, inv, 1.0), inv, inv);
+    u = fma(r0, ayy, -(c * r1)) * inv;
+    w = fma(axx, r1, -(c * r0)) * inv;
+    gm = fma(-Dy, w, fma(-Dx, u, r2)) * inv_g;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_rhs: b = (-P Dxt, -P Dyt, -Dt) on the interior (OF.py:889,938,962).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_rhs(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni,
@@ -258,18 +374,27 @@ __global__ __launch_bounds__(NT) void k_gs0(const double* __restrict__ frames, s
     int fidx = pair;
     if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
-    PixCoef k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, p, q, quirks);
+    const double* c = frames + (size_t)fidx * frame_stride + (size_t)(p + 1) * Nj + (q + 1);
+    const double im[9] = {c[-Nj - 1], c[-Nj], c[-Nj + 1], c[-1], c[0], c[1], c[Nj - 1], c[Nj], c[Nj + 1]};
+    // neighbours with folded ghosts, corner factors applied by gs0_point
+    const double* xp = x + off;
+    const bool oU = p - 1 < 0, oD = p + 1 >= ni, oL = q - 1 < 0, oR = q + 1 >= nj;
+    const size_t rU = (size_t)fold(p - 1, ni) * nj, rC = (size_t)p * nj, rD = (size_t)fold(p + 1, ni) * nj;
+    const int qL = fold(q - 1, nj), qR = fold(q + 1, nj);
     Nbr n;
-    load_nbr(x + off, npts, ni, nj, p, q, n);
-    double y0, y1, y2;
-    offdiag0(k, alpha, beta, n, y0, y1, y2);
-    const double P = k.P;
-    double r0 = b[off + idx] - y0, r1 = b[off + npts + idx] - y1, r2 = b[off + 2 * npts + idx] - y2;
-    double axx = P * (k.Dxx - 2 * P) - 4 * alpha, ayy = P * (k.Dyy - 2 * P) - 4 * alpha, c = P * k.Dxy;
-    double inv = 1.0 / (axx * ayy - c * c);
-    double u = (r0 * ayy - c * r1) * inv;
-    double w = (axx * r1 - c * r0) * inv;
-    double g = (r2 - k.Dx * u - k.Dy * w) / (-1 - 4 * beta);
+    n.u[0] = xp[rU + qL]; n.w[0] = xp[npts + rU + qL];
+    n.u[1] = xp[rU + q];  n.w[1] = xp[npts + rU + q];  n.g[1] = xp[2 * npts + rU + q];
+    n.u[2] = xp[rU + qR]; n.w[2] = xp[npts + rU + qR];
+    n.u[3] = xp[rC + qL]; n.w[3] = xp[npts + rC + qL]; n.g[3] = xp[2 * npts + rC + qL];
+    n.u[5] = xp[rC + qR]; n.w[5] = xp[npts + rC + qR]; n.g[5] = xp[2 * npts + rC + qR];
+    n.u[6] = xp[rD + qL]; n.w[6] = xp[npts + rD + qL];
+    n.u[7] = xp[rD + q];  n.w[7] = xp[npts + rD + q];  n.g[7] = xp[2 * npts + rD + q];
+    n.u[8] = xp[rD + qR]; n.w[8] = xp[npts + rD + qR];
+    const double sUL = (oU && oL) ? 2.0 : 1.0, sUR = (oU && oR) ? 2.0 : 1.0;
+    const double sDL = (oD && oL) ? 2.0 : 1.0, sDR = (oD && oR) ? 2.0 : 1.0;
+    double u, w, g;
+    gs0_point<true>(im, n, sUL, sUR, sDL, sDR, alpha, beta, 1.0 / (-1 - 4 * beta), quirks, b[off + idx], b[off + npts + idx],
+                    b[off + 2 * npts + idx], u, w, g);
     x[off + idx] = u;
     x[off + npts + idx] = w;
     x[off + 2 * npts + idx] = g;
@@ -279,11 +404,9 @@ __global__ __launch_bounds__(NT) void k_gs0(const double* __restrict__ frames, s
 // Stored-stencil levels (Galerkin coarse operators): C[pair][(a*3+b)*9 + r*3+c][npts].
 // ------------------------------------------------------------------------------------------
 template <typename CT, typename VT>
-__device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t npts, const VT* __restrict__ x,
+__device__ __forceinline__ void stencil_offdiag(const CoefSet<CT>& cs, size_t npts, const VT* __restrict__ x,
                                                 int ni, int nj, int p, int q, double& y0, double& y1, double& y2,
                                                 bool include_diag) {
-    const CLay L(ni, nj);
-    const size_t idx = L.idx(p, q), cps = L.plane;
     y0 = y1 = y2 = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -296,24 +419,27 @@ __device__ __forceinline__ void stencil_offdiag(const CT* __restrict__ C, size_t
             if (!include_diag && a == 1 && bb == 1) continue;
             size_t t = (size_t)tp * nj + tq;
             double xu = (double)x[t], xw = (double)x[npts + t], xg = (double)x[2 * npts + t];
-            const CT* cb = C + (size_t)((a * 3 + bb) * 9) * cps + idx;
-            y0 += (double)cb[0] * xu + (double)cb[cps] * xw + (double)cb[2 * cps] * xg;
-            y1 += (double)cb[3 * cps] * xu + (double)cb[4 * cps] * xw + (double)cb[5 * cps] * xg;
-            y2 += (double)cb[6 * cps] * xu + (double)cb[7 * cps] * xw + (double)cb[8 * cps] * xg;
+            const int t0 = (a * 3 + bb) * 9;
+            y0 += cs.get(t0 + 0) * xu + cs.get(t0 + 1) * xw + cs.get(t0 + 2) * xg;
+            y1 += cs.get(t0 + 3) * xu + cs.get(t0 + 4) * xw + cs.get(t0 + 5) * xg;
+            y2 += cs.get(t0 + 6) * xu + cs.get(t0 + 7) * xw + cs.get(t0 + 8) * xg;
         }
     }
 }
 
 template <typename CT, int MODE, typename VT>
-__global__ __launch_bounds__(NT) void k_apply(const CT* __restrict__ C, int ni, int nj, const VT* __restrict__ x,
-                                              const VT* __restrict__ b, VT* __restrict__ y,
+__global__ __launch_bounds__(NT) void k_apply(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj,
+                                              const VT* __restrict__ x, const VT* __restrict__ b, VT* __restrict__ y,
                                               const int* __restrict__ active) {
     int q = blockIdx.x * BX + threadIdx.x, p = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
     if (active && !active[pair]) return;
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
+    const CLay L(ni, nj);
+    CoefSet<CT> cs;
+    cs.load(C + (size_t)pair * CoefFmt<CT>::PLANES * L.plane + L.idx(p, q), L.plane);
     double y0, y1, y2;
-    stencil_offdiag<CT, VT>(C + (size_t)pair * 81 * CLay(ni, nj).plane, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
+    stencil_offdiag<CT, VT>(cs, npts, x + off, ni, nj, p, q, y0, y1, y2, true);
     if (MODE == 1) {
         y0 = (double)b[off + idx] - y0;
         y1 = (double)b[off + npts + idx] - y1;
@@ -335,8 +461,8 @@ __device__ __forceinline__ void solve3(const double* D, double r0, double r1, do
 }
 
 template <typename CT>
-__global__ __launch_bounds__(NT) void k_gs(const CT* __restrict__ C, int ni, int nj, double* __restrict__ x,
-                                           const double* __restrict__ b, int colour,
+__global__ __launch_bounds__(NT) void k_gs(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj,
+                                           double* __restrict__ x, const double* __restrict__ b, int colour,
                                            const int* __restrict__ active) {
     int pair = blockIdx.z;
     if (active && !active[pair]) return;
@@ -345,13 +471,13 @@ __global__ __launch_bounds__(NT) void k_gs(const CT* __restrict__ C, int ni, int
     if (p >= ni || q >= nj) return;
     size_t npts = (size_t)ni * nj, idx = (size_t)p * nj + q, off = (size_t)pair * 3 * npts;
     const CLay L(ni, nj);
-    const CT* Cp = C + (size_t)pair * 81 * L.plane;
+    CoefSet<CT> cs;
+    cs.load(C + (size_t)pair * CoefFmt<CT>::PLANES * L.plane + L.idx(p, q), L.plane);
     double y0, y1, y2;
-    stencil_offdiag<CT, double>(Cp, npts, x + off, ni, nj, p, q, y0, y1, y2, false);
+    stencil_offdiag<CT, double>(cs, npts, x + off, ni, nj, p, q, y0, y1, y2, false);
     double D[9];
-    const size_t cidx = L.idx(p, q);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) D[t] = (double)Cp[(size_t)(36 + t) * L.plane + cidx];
+    for (int t = 0; t < 9; ++t) D[t] = cs.get(36 + t);
     double x0, x1, x2;
     solve3(D, b[off + idx] - y0, b[off + npts + idx] - y1, b[off + 2 * npts + idx] - y2, x0, x1, x2);
     x[off + idx] = x0;
@@ -442,8 +568,8 @@ __global__ __launch_bounds__(NT) void k_prolong_add(VT* __restrict__ fine, int n
 template <typename CTF, typename CTC, bool LEVEL0>
 __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ frames, size_t frame_stride, int Nj,
                                                  double alpha, double beta, int quirks,
-                                                 const CTF* __restrict__ Cf, int nfi, int nfj,
-                                                 CTC* __restrict__ Cc, int nci, int ncj,
+                                                 const typename CoefFmt<CTF>::word_t* __restrict__ Cf, int nfi, int nfj,
+                                                 typename CoefFmt<CTC>::word_t* __restrict__ Cc, int nci, int ncj,
                                                  const PairParam* __restrict__ pp) {
     int cq = blockIdx.x * BX + threadIdx.x, cp = blockIdx.y * BY + threadIdx.y;
     int pair = blockIdx.z;
@@ -452,11 +578,15 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
     if (LEVEL0 && pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     const CLay Lf(nfi, nfj), Lc(nci, ncj);
     const size_t nf = Lf.plane, nc = Lc.plane;
-    double acc[9][9];
+    // float32 / bfloat16 stencils are accumulated in float32 (preconditioner data: the <= 36 terms per entry lose ~1e-6
+    // relative; FP32 FMAs issue at twice the FP64 rate and this kernel is FMA-bound); the fine blocks themselves are
+    // evaluated from the image in float64
+    typedef typename std::conditional<std::is_same<CTC, double>::value, double, float>::type AT;
+    AT acc[9][9];
 #pragma unroll
     for (int d = 0; d < 9; ++d)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[d][t] = 0.0;
+        for (int t = 0; t < 9; ++t) acc[d][t] = (AT)0;
 #pragma unroll
     for (int fi = -1; fi <= 1; ++fi) {
         const int fp = 2 * cp + fi;
@@ -468,8 +598,9 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
             if (fq < 0 || fq >= nfj) continue;
             const double wf = wfi * pweight(fq, cq, ncj);
             PixCoef k;
+            CoefSet<CTF> fs;   // the fine point's stored stencil (levels >= 1)
             if (LEVEL0) k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, fp, fq, quirks);
-            const CTF* fb = LEVEL0 ? nullptr : Cf + (size_t)pair * 81 * nf + Lf.idx(fp, fq);
+            else fs.load(Cf + (size_t)pair * CoefFmt<CTF>::PLANES * nf + Lf.idx(fp, fq), nf);
 #pragma unroll
             for (int oi = -1; oi <= 1; ++oi) {
                 const int gp = fp + oi;
@@ -478,13 +609,15 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
                 for (int oj = -1; oj <= 1; ++oj) {
                     const int gq = fq + oj;
                     if (gq < 0 || gq >= nfj) continue;
-                    double blk[9];
+                    AT blk[9];
                     if (LEVEL0) {
-                        folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk);
-                    } else {
-                        const CTF* cb = fb + (size_t)(((oi + 1) * 3 + (oj + 1)) * 9) * nf;
+                        double blk64[9];
+                        folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk64);
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) blk[t] = (double)cb[(size_t)t * nf];
+                        for (int t = 0; t < 9; ++t) blk[t] = (AT)blk64[t];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) blk[t] = (AT)fs.get(((oi + 1) * 3 + (oj + 1)) * 9 + t);
                     }
 #pragma unroll
                     for (int a = -1; a <= 1; ++a) {
@@ -500,7 +633,7 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
                             if (tj < -1 || tj > 1) continue;
                             const int Dq = cq + b;
                             if (Dq < 0 || Dq >= ncj) continue;
-                            const double w = wf * wgi * pweight(gq, Dq, ncj);
+                            const AT w = (AT)(wf * wgi * pweight(gq, Dq, ncj));
 #pragma unroll
                             for (int t = 0; t < 9; ++t) acc[(a + 1) * 3 + (b + 1)][t] += w * blk[t];
                         }
@@ -509,11 +642,34 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
             }
         }
     }
-    CTC* out = Cc + (size_t)pair * 81 * nc + Lc.idx(cp, cq);
+    typename CoefFmt<CTC>::word_t* out = Cc + (size_t)pair * CoefFmt<CTC>::PLANES * nc + Lc.idx(cp, cq);
+    if constexpr (std::is_same<CTC, CoefB16>::value) {
+        // off-diagonal blocks -> bfloat16; their rounding errors go to the diagonal block (block row sums are kept)
+        float diag[9];
 #pragma unroll
-    for (int d = 0; d < 9; ++d)
+        for (int t = 0; t < 9; ++t) diag[t] = 0.25f * acc[4][t];
+        uint32_t h[72];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) out[(size_t)(d * 9 + t) * nc] = (CTC)(0.25 * acc[d][t]);
+        for (int d = 0; d < 9; ++d) {
+            if (d == 4) continue;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = 0.25f * acc[d][t];
+                const uint32_t hb = bf16_round(v);
+                diag[t] += v - __uint_as_float(hb << 16);
+                h[(d < 4 ? d : d - 1) * 9 + t] = hb;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 36; ++j) out[(size_t)j * nc] = h[2 * j] | (h[2 * j + 1] << 16);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[(size_t)(36 + t) * nc] = __float_as_uint(diag[t]);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 9; ++d)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) out[(size_t)(d * 9 + t) * nc] = (CTC)((AT)0.25 * acc[d][t]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -521,7 +677,7 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
 // stack), applied as a mat-vec in every V-cycle.  W is [nd][2 nd] row-major in global memory (L2).
 // ------------------------------------------------------------------------------------------
 template <typename CT>
-__global__ void k_coarse_build(const CT* __restrict__ C, int ni, int nj, double* __restrict__ W) {
+__global__ void k_coarse_build(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, double* __restrict__ W) {
     int pair = blockIdx.x;
     int npts = ni * nj, nd = 3 * npts;
     double* Wp = W + (size_t)pair * nd * 2 * nd;
@@ -531,18 +687,18 @@ __global__ void k_coarse_build(const CT* __restrict__ C, int ni, int nj, double*
     }
     __syncthreads();
     const CLay L(ni, nj);
-    const CT* Cp = C + (size_t)pair * 81 * L.plane;
+    const typename CoefFmt<CT>::word_t* Cp = C + (size_t)pair * CoefFmt<CT>::PLANES * L.plane;
     for (int t = threadIdx.x; t < 81 * npts; t += blockDim.x) {
         int plane = t / npts, pt = t % npts;
         int ab = plane / 9, rc = plane % 9;
         int a = ab / 3 - 1, b = ab % 3 - 1, r = rc / 3, c = rc % 3;
         int p = pt / nj, q = pt % nj, tp = p + a, tq = q + b;
         if (tp < 0 || tp >= ni || tq < 0 || tq >= nj) continue;
-        Wp[(size_t)(r * npts + pt) * 2 * nd + (c * npts + tp * nj + tq)] = (double)Cp[(size_t)plane * L.plane + L.idx(p, q)];
+        Wp[(size_t)(r * npts + pt) * 2 * nd + (c * npts + tp * nj + tq)] = coef_at<CT>(Cp, L.plane, L.idx(p, q), plane);
     }
 }
 
-constexpr int COARSE_ND_MAX = 3 * 9 * 9;   // 3 fields on at most 9 x 9 points (COARSEST_MAX in vof.hip)
+constexpr int COARSE_ND_MAX = 3 * 9 * 9;   // 3 fields on at most 9 x 9 points (upper bound of COARSEST_MAX in vof.hip)
 
 // 1024 threads = 16 waves: wave 0 finds the pivot, the scaled pivot row and the multiplier column are staged in LDS,
 // then wave w eliminates rows w, w + 16, ... (64 columns per step, coalesced; rows with a zero multiplier are skipped -
@@ -1303,12 +1459,12 @@ struct SweepFine {
     const PairParam* pp;   // per-pair overrides (virtual pairs) or nullptr
     static constexpr bool kHasImage = true;
     static constexpr int kPrefetch = 0;   // no per-point coefficient planes
-    typedef float coef_t;
-    __device__ __forceinline__ void prefetch(const SweepCols&, size_t, int, coef_t*) const {}
+    struct cset_t { __device__ __forceinline__ void clear() {} };
+    __device__ __forceinline__ void prefetch(const SweepCols&, size_t, int, cset_t&) const {}
 
     template <class G, typename VT>
     __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs, const double* im,
-                                           int /*pair*/, const coef_t* /*cf*/, double b0, double b1, double b2,
+                                           int /*pair*/, const cset_t& /*cf*/, double b0, double b1, double b2,
                                            double& u, double& w, double& gm) const {
         constexpr int W = G::W;
         const double* r0 = im + rw.iU;
@@ -1317,13 +1473,6 @@ struct SweepFine {
         double imm = r0[cc.iL], im0 = r0[cc.iC], imp = r0[cc.iR];
         double i0m = r1[cc.iL], i00 = r1[cc.iC], i0p = r1[cc.iR];
         double ipm = r2[cc.iL], ip0 = r2[cc.iC], ipp = r2[cc.iR];
-        PixCoef k;
-        k.P = i00;
-        k.Dx = (ip0 - im0) / 2;
-        k.Dy = quirks ? k.Dx : (i0p - i0m) / 2;
-        k.Dxx = ip0 + im0 - 2 * i00;
-        k.Dyy = i0p + i0m - 2 * i00;
-        k.Dxy = (ipp - ipm - imp + imm) / 4;
         const VT* ru = xs + rw.xU;
         const VT* rc = xs + rw.xC;
         const VT* rd = xs + rw.xD;
@@ -1331,58 +1480,52 @@ struct SweepFine {
         const double sUL = (rw.oU && cc.oL) ? 2.0 : 1.0, sUR = (rw.oU && cc.oR) ? 2.0 : 1.0;
         const double sDL = (rw.oD && cc.oL) ? 2.0 : 1.0, sDR = (rw.oD && cc.oR) ? 2.0 : 1.0;
         Nbr n;
-        n.u[0] = sUL * (double)ru[cc.cL]; n.w[0] = sUL * (double)ru[W + cc.cL];
-        n.u[1] = (double)ru[cc.cC];       n.w[1] = (double)ru[W + cc.cC];       n.g[1] = (double)ru[2 * W + cc.cC];
-        n.u[2] = sUR * (double)ru[cc.cR]; n.w[2] = sUR * (double)ru[W + cc.cR];
-        n.u[3] = (double)rc[cc.cL];       n.w[3] = (double)rc[W + cc.cL];       n.g[3] = (double)rc[2 * W + cc.cL];
-        n.u[5] = (double)rc[cc.cR];       n.w[5] = (double)rc[W + cc.cR];       n.g[5] = (double)rc[2 * W + cc.cR];
-        n.u[6] = sDL * (double)rd[cc.cL]; n.w[6] = sDL * (double)rd[W + cc.cL];
-        n.u[7] = (double)rd[cc.cC];       n.w[7] = (double)rd[W + cc.cC];       n.g[7] = (double)rd[2 * W + cc.cC];
-        n.u[8] = sDR * (double)rd[cc.cR]; n.w[8] = sDR * (double)rd[W + cc.cR];
-        double y0, y1, y2;
-        offdiag0(k, alpha, beta, n, y0, y1, y2);
-        const double P = k.P;
-        double r0_ = b0 - y0, r1_ = b1 - y1, r2_ = b2 - y2;
-        double axx = P * (k.Dxx - 2 * P) - 4 * alpha, ayy = P * (k.Dyy - 2 * P) - 4 * alpha, c = P * k.Dxy;
-        double inv = 1.0 / (axx * ayy - c * c);
-        u = (r0_ * ayy - c * r1_) * inv;
-        w = (axx * r1_ - c * r0_) * inv;
-        gm = (r2_ - k.Dx * u - k.Dy * w) / (-1 - 4 * beta);
+        n.u[0] = (double)ru[cc.cL]; n.w[0] = (double)ru[W + cc.cL];
+        n.u[1] = (double)ru[cc.cC]; n.w[1] = (double)ru[W + cc.cC]; n.g[1] = (double)ru[2 * W + cc.cC];
+        n.u[2] = (double)ru[cc.cR]; n.w[2] = (double)ru[W + cc.cR];
+        n.u[3] = (double)rc[cc.cL]; n.w[3] = (double)rc[W + cc.cL]; n.g[3] = (double)rc[2 * W + cc.cL];
+        n.u[5] = (double)rc[cc.cR]; n.w[5] = (double)rc[W + cc.cR]; n.g[5] = (double)rc[2 * W + cc.cR];
+        n.u[6] = (double)rd[cc.cL]; n.w[6] = (double)rd[W + cc.cL];
+        n.u[7] = (double)rd[cc.cC]; n.w[7] = (double)rd[W + cc.cC]; n.g[7] = (double)rd[2 * W + cc.cC];
+        n.u[8] = (double)rd[cc.cR]; n.w[8] = (double)rd[W + cc.cR];
+        const double imv[9] = {imm, im0, imp, i0m, i00, i0p, ipm, ip0, ipp};
+        gs0_point<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, 1.0 / (-1 - 4 * beta), quirks, b0, b1, b2, u, w, gm);
     }
 };
 
 // ---- policy: stored Galerkin stencil (levels >= 1) -------------------------------------------
 template <typename CT>
 struct SweepStored {
-    const CT* C;  // [pair][81][colour-split plane]
-    size_t plane; // CLay(ni, nj).plane
+    typedef typename CoefFmt<CT>::word_t word_t;
+    const word_t* C;  // [pair][PLANES][colour-split plane]
+    size_t plane;     // CLay(ni, nj).plane
     static constexpr bool kHasImage = false;
     // dummies so the kernel template compiles for both policies
     const double* frames = nullptr;
     size_t frame_stride = 0;
     int Nj = 0;
 
-    // float stencils: the 81 coefficients of the NEXT step's point are loaded into registers before the step
-    // barrier (the registers of the current step are dead by then), so their latency overlaps the barrier and
-    // the next step's row traffic.  double stencils (162 registers) are loaded at use.
+    // 32-bit formats (float, packed bfloat16): the coefficient words of the NEXT step's point are loaded into registers
+    // before the step barrier (the registers of the current step are dead by then), so their latency overlaps the barrier
+    // and the next step's row traffic.  double stencils (162 registers) are loaded at use.
 #ifdef SW_NO_PREFETCH
     static constexpr int kPrefetch = 0;
 #else
-    static constexpr int kPrefetch = sizeof(CT) == 4 ? 81 : 0;
+    static constexpr int kPrefetch = sizeof(word_t) == 4 ? 1 : 0;
 #endif
-    typedef CT coef_t;
-    __device__ __forceinline__ void prefetch(const SweepCols& cc, size_t rowpart, int pair, coef_t* cf) const {
-        const CT* sp = C + (size_t)pair * 81 * plane + rowpart + cc.cq;
-#pragma unroll
-        for (int t = 0; t < 81; ++t) cf[t] = sp[(size_t)t * plane];
+    typedef CoefSet<CT> cset_t;
+    __device__ __forceinline__ void prefetch(const SweepCols& cc, size_t rowpart, int pair, cset_t& cf) const {
+        cf.load(C + (size_t)pair * CoefFmt<CT>::PLANES * plane + rowpart + cc.cq, plane);
     }
 
     template <class G, typename VT>
     __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs,
-                                           const double* /*im*/, int pair, const coef_t* cf, double b0, double b1,
+                                           const double* /*im*/, int pair, const cset_t& cfp, double b0, double b1,
                                            double b2, double& u, double& w, double& gm) const {
         constexpr int W = G::W;
-        const CT* sp = C + (size_t)pair * 81 * plane + rw.cp + cc.cq;
+        cset_t cl;
+        if (!kPrefetch) cl.load(C + (size_t)pair * CoefFmt<CT>::PLANES * plane + rw.cp + cc.cq, plane);
+        const cset_t& cf = kPrefetch ? cfp : cl;
         const int rowo[3] = {rw.pU, rw.pC, rw.pD};
         const int colo[3] = {cc.uL, cc.cC, cc.uR};
         double y0 = 0, y1 = 0, y2 = 0;
@@ -1394,17 +1537,14 @@ struct SweepStored {
                 if (a == 1 && bb == 1) continue;
                 double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
                 const int t0 = (a * 3 + bb) * 9;
-                double c9[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) c9[t] = kPrefetch ? (double)cf[t0 + t] : (double)sp[(size_t)(t0 + t) * plane];
-                y0 += c9[0] * xu + c9[1] * xw + c9[2] * xg;
-                y1 += c9[3] * xu + c9[4] * xw + c9[5] * xg;
-                y2 += c9[6] * xu + c9[7] * xw + c9[8] * xg;
+                y0 += cf.get(t0 + 0) * xu + cf.get(t0 + 1) * xw + cf.get(t0 + 2) * xg;
+                y1 += cf.get(t0 + 3) * xu + cf.get(t0 + 4) * xw + cf.get(t0 + 5) * xg;
+                y2 += cf.get(t0 + 6) * xu + cf.get(t0 + 7) * xw + cf.get(t0 + 8) * xg;
             }
         }
         double D[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) D[t] = kPrefetch ? (double)cf[36 + t] : (double)sp[(size_t)(36 + t) * plane];
+        for (int t = 0; t < 9; ++t) D[t] = cf.get(36 + t);
         solve3(D, b0 - y0, b1 - y1, b2 - y2, u, w, gm);
     }
 };
@@ -1590,11 +1730,8 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
     const int stage_row_off = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
     const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
     double bn0 = 0, bn1 = 0, bn2 = 0;  // b of the stage's point for the NEXT step (prefetched)
-    typename Pol::coef_t cf[Pol::kPrefetch ? Pol::kPrefetch : 1];   // coefficients of the next step's point
-    if (Pol::kPrefetch) {
-#pragma unroll
-        for (int t = 0; t < (Pol::kPrefetch ? Pol::kPrefetch : 1); ++t) cf[t] = 0;
-    }
+    typename Pol::cset_t cf;   // coefficients of the next step's point
+    if (Pol::kPrefetch) cf.clear();
     const int s_end = TI / 2 + 4;
     int slotA = sw_slot(-2);   // ring slot of relative row e + 2, advanced by 2 per step
     for (int s = -2; s <= s_end; ++s, slotA = sw_wrap(slotA + 2)) {
@@ -1747,6 +1884,273 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
 }
 
 // ==========================================================================================
+// k_sweep0: the fused 4-colour sweep of level 0 (matrix-free), the north-star kernel.  Same schedule, strip geometry
+// (120 owned + 2 x 4 halo columns, 4 colour waves, 12-row ring, bands of TI rows) and results as
+// k_sweep<SweepFine, GeoA> above - bit for bit - but the row loop is rebuilt around its instruction budget (the PMC
+// profile of the generic kernel showed more scalar than vector instructions per wave and a fifth of its time lost to
+// the compute stage not overlapping the row traffic):
+//  * x rows and image rows share ONE ring row (3 x 128 VT + 132 doubles), so a single running byte offset per row
+//    addresses both; ring offsets and global row offsets are advanced incrementally (no per-step multiplications);
+//  * the steps of a band in which every row touched is an interior row that exists (58 of 71 steps of a 128-row band) run
+//    a predicate-free body: no row range tests, no ghost-row folding, no corner factors (corner pixels only occur in
+//    edge steps); the few edge steps at the top / bottom of a band run the general body;
+//  * the point update is gs0_point (no IEEE divisions);
+//  * from-zero / with-interpolated-correction variants are compile-time (EC, FROM_ZERO).
+// ==========================================================================================
+struct Fine0 {
+    const double* frames;  // previous frame of pair 0
+    size_t frame_stride;
+    int Nj;
+    double alpha, beta;
+    int quirks;
+    const PairParam* pp;   // per-pair overrides (virtual pairs) or nullptr
+};
+constexpr int S0_W = 128, S0_IW = 132, S0_OUT = 120, S0_THREADS = 256;
+__host__ __device__ constexpr int s0_row_bytes(int vt_bytes) { return 3 * S0_W * vt_bytes + S0_IW * 8; }
+
+template <typename VT, bool EC, bool FROM_ZERO>
+__global__ __launch_bounds__(S0_THREADS) void k_sweep0(Fine0 pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
+                                                       const VT* __restrict__ x_in, VT* __restrict__ x_out,
+                                                       const VT* __restrict__ b, const int* __restrict__ active,
+                                                       const VT* __restrict__ ecoarse, int nci, int ncj) {
+    constexpr int W = S0_W, IW = S0_IW, OUT = S0_OUT;
+    constexpr int VB = (int)sizeof(VT);
+    constexpr int FB = W * VB;                 // field stride inside a ring row (bytes)
+    constexpr int XB = 3 * FB;                 // image part of a ring row starts here
+    constexpr int RSB = s0_row_bytes(VB);      // ring row stride (bytes)
+    constexpr int RINGB = SW_RING * RSB;
+    constexpr int CRW = W / 2 + 2;             // coarse ring width
+    extern __shared__ double sw_lds[];
+    char* ring = reinterpret_cast<char*>(sw_lds);
+    VT* cr = reinterpret_cast<VT*>(ring + RINGB);   // [3][3][CRW] (EC only)
+    const unsigned nblocks = (unsigned)nx * ny * nz;
+    unsigned lb = blockIdx.x;
+    if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
+    const int bx = lb % nx, by = (lb / nx) % ny;
+    const int pair = lb / (nx * ny);
+    if (active && !active[pair]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p0 = by * TI - po;                 // true row of relative row 0
+    const int qs = bx * OUT - po - SW_HALO;      // true column of local column 0
+    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const VT* xin = FROM_ZERO ? nullptr : x_in + off;
+    VT* xout = x_out + off;
+    const VT* bp = b + off;
+    const size_t ncpts = (size_t)nci * ncj;
+    const VT* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
+    double alpha = pol.alpha, beta = pol.beta;
+    int fidx = pair;
+    if (pol.pp) { alpha = pol.pp[pair].alpha; beta = pol.pp[pair].beta; fidx = pol.pp[pair].frame; }
+    const double* img = pol.frames + (size_t)fidx * pol.frame_stride;
+    const int Nj = pol.Nj, quirks = pol.quirks;
+    const double inv_g = 1.0 / (-1 - 4 * beta);
+
+    auto cs = [](int lc) { return (lc & 1) * (W / 2) + (lc >> 1); };      // parity-split column slots
+    auto ci = [](int lci) { return (lci & 1) * (IW / 2) + (lci >> 1); };
+    // ---- stage of this wave: colour = wave; valid local columns 2..126, 3..125, 4..124, 5..123
+    const int lc = 2 * lane + (wave & 1);
+    const bool lane_on = (lc >= 2 + wave) && (lc <= W - 2 - wave);
+    const int q = qs + lc;
+    const bool col_ok = lane_on && q >= 0 && q < nj;
+    const int qc = col_ok ? q : 0, lcc = col_ok ? lc : 2;   // keep the index math of masked lanes in range
+    const bool oL = qc - 1 < 0, oR = qc + 1 >= nj;
+    const int uL = cs(lcc - 1) * VB, uR = cs(lcc + 1) * VB;
+    const int xC = cs(lcc) * VB, xL = oL ? uR : uL, xR = oR ? uL : uR;   // ghost column -1 mirrors column 1, n mirrors n-2
+    const int iL = XB + ci(lcc) * 8, iC = XB + ci(lcc + 1) * 8, iR = XB + ci(lcc + 2) * 8;
+    const size_t bcol = (size_t)qc;
+    const int sro = (wave == 0) ? 0 : (wave == 1) ? -2 : (wave == 2) ? -5 : -7;   // row of the stage relative to e
+    const int rr_lo = (wave < 2) ? 0 : 1, rr_hi = (wave < 2) ? TI : TI - 1;
+    // ---- row traffic: waves {0,1} own row A (e + 2), waves {2,3} row B (e + 3); a thread owns one column, 3 fields
+    const int crow = wave >> 1;
+    const int ccol = tid & 127;
+    const int cq = qs + ccol;
+    const bool ccv = cq >= 0 && cq < nj;
+    const bool cown = ccv && ccol >= SW_HALO && ccol < SW_HALO + OUT;
+    const int clds = cs(ccol) * VB;
+    const size_t cqg = ccv ? (size_t)cq : 0;
+    const int fc0 = qs + ccol, fc1 = qs + 128 + ccol;   // full-image columns of image-ring columns ccol, 128 + ccol
+    const bool iv0 = fc0 >= 0 && fc0 <= nj + 1, iv1 = ccol < 2 && fc1 >= 0 && fc1 <= nj + 1;
+    const int ilds0 = XB + ci(ccol) * 8, ilds1 = XB + ci(ccol < 2 ? 128 + ccol : 0) * 8;
+    const size_t fc0g = iv0 ? (size_t)fc0 : 0, fc1g = iv1 ? (size_t)fc1 : 0;
+    // ---- coarse-correction ring (EC): thread <-> (field, coarse column) of the row being prefetched
+    const int cqs = qs >> 1;
+    const int crf = tid / CRW, crc = tid % CRW;
+    const bool cr_on = EC && tid < 3 * CRW;
+    const int crq = cqs + crc;
+    const bool cr_cv = cr_on && crq >= 0 && crq < ncj;
+    const int ilcq = (int)(cqg >> 1) - cqs;
+    const bool ipj = ccv && (cq & 1) && ((cq >> 1) + 1 < ncj);
+    auto cr_slot = [](int k) { return ((k % 3) + 3) % 3; };
+    if (EC) {   // prologue: the two coarse rows the first load-in step needs
+        const int k0 = (p0 - 2) >> 1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int k = k0 + d;
+            VT v = (VT)0;
+            if (cr_cv && k >= 0 && k < nci) v = ec[(size_t)crf * ncpts + (size_t)k * ncj + crq];
+            if (cr_on) cr[(cr_slot(k) * 3 + crf) * CRW + crc] = v;
+        }
+        __syncthreads();
+    }
+
+    // ---- running state (advanced by two rows per step)
+    const int s_end = TI / 2 + 4;
+    auto wrapB = [](int t) { return t >= RINGB ? t - RINGB : t; };
+    int ringR = wrapB(sw_slot(-2) * RSB + crow * RSB);                        // ring row of relative row e + 2 + crow
+    int rowC = wrapB(sw_slot(-2) * RSB + ((sro - 2 + 2 * SW_RING) % SW_RING) * RSB);   // ring row of the stage's row e + sro
+    rowC = wrapB(rowC);
+    // global row offsets in elements (64-bit; never dereferenced while out of range)
+    long long gL = (long long)(p0 - 4 + 2 + crow) * nj;        // x row being loaded: p0 + e + 2 + crow
+    long long gW = (long long)(p0 - 4 - 10 + crow) * nj;       // x row being written out: p0 + e - 10 + crow
+    long long gI = (long long)(p0 - 4 + 3 + crow) * Nj;        // image row being loaded: p0 + e + 2 + crow + 1 (full image)
+    long long gB = (long long)(p0 - 4 + 2 + sro) * nj;         // b row prefetched: p0 + e + 2 + sro
+    // steps whose rows are all interior rows that exist (see the header): e in [e_lo, e_hi]
+    const int e_lo = max(10, 10 - p0), e_hi = min(TI - 2, ni - p0 - 4);
+    double bn0 = 0, bn1 = 0, bn2 = 0;   // b of the stage's point for the NEXT step (prefetched)
+
+    auto step = [&](auto edge_tag, const int e) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        VT lx0 = (VT)0, lx1 = (VT)0, lx2 = (VT)0;
+        double li0 = 0.0, li1 = 0.0;
+        VT crv = (VT)0;
+        const bool do_load = EDGE ? (e + 2 <= TI + 1) : true;
+        const int pL = p0 + e + 2 + crow;
+        const int knew = ((p0 + e + 4) >> 1) + 1;
+        // (1) write-out of the row that became final: relative row e - 10 + crow
+        {
+            const int rrW = e - 10 + crow;
+            const bool rowok = EDGE ? (rrW >= 0 && rrW < TI && p0 + rrW >= 0 && p0 + rrW < ni) : true;
+            if (rowok && cown) {
+                VT* orow = xout + gW + cqg;
+                const char* lrow = ring + ringR + clds;
+                orow[0] = *reinterpret_cast<const VT*>(lrow);
+                orow[npts] = *reinterpret_cast<const VT*>(lrow + FB);
+                orow[2 * npts] = *reinterpret_cast<const VT*>(lrow + 2 * FB);
+            }
+        }
+        // (2) global loads of relative row e + 2 + crow into registers
+        {
+            const bool rowok = EDGE ? (do_load && pL >= 0 && pL < ni) : true;
+            if (!FROM_ZERO) {
+                if (rowok && ccv) {
+                    const VT* irow = xin + gL + cqg;
+                    lx0 = irow[0]; lx1 = irow[npts]; lx2 = irow[2 * npts];   // (EC: the correction is added in (5))
+                }
+            }
+            if (EC) {   // coarse row needed by the NEXT step
+                if (cr_cv && knew >= 0 && knew < nci) crv = ec[(size_t)crf * ncpts + (size_t)knew * ncj + crq];
+            }
+            const bool irowok = EDGE ? (do_load && pL + 1 >= 0 && pL + 1 <= ni + 1) : true;
+            if (irowok) {
+                const double* frow = img + gI;
+                if (iv0) li0 = frow[fc0g];
+                if (iv1) li1 = frow[fc1g];
+            }
+        }
+        // (3) this step's b (prefetched during the previous step) and the prefetch for the next step
+        const double b0 = bn0, b1 = bn1, b2 = bn2;
+        {
+            const int rrn = e + 2 + sro;
+            const bool rowok = EDGE ? (rrn >= rr_lo && rrn <= rr_hi && p0 + rrn >= 0 && p0 + rrn < ni) : true;
+            if (rowok && col_ok) {
+                const VT* brow = bp + gB + bcol;
+                bn0 = (double)brow[0]; bn1 = (double)brow[npts]; bn2 = (double)brow[2 * npts];
+            }
+        }
+        // (4) the stage of this wave: colour `wave` on relative row e + sro
+#ifndef SW_EXP_NOCOMPUTE
+        {
+            const int rr = e + sro, p = p0 + rr;
+            const bool rowok = EDGE ? (rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) : true;
+            if (rowok && col_ok) {
+                const int rowU = rowC >= RSB ? rowC - RSB : rowC + RINGB - RSB;
+                const int rowD = wrapB(rowC + RSB);
+                const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
+                const char* ru = ring + (oU ? rowD : rowU);   // ghost row -1 mirrors row 1, ghost row n mirrors row n-2
+                const char* rc = ring + rowC;
+                const char* rd = ring + (oD ? rowU : rowD);
+                const char* iu = ring + rowU;                 // the image has real border rows: no folding
+                const char* id = ring + rowD;
+                auto X = [](const char* r, int o) { return (double)*reinterpret_cast<const VT*>(r + o); };
+                auto I = [](const char* r, int o) { return *reinterpret_cast<const double*>(r + o); };
+                const double imv[9] = {I(iu, iL), I(iu, iC), I(iu, iR), I(rc, iL), I(rc, iC), I(rc, iR), I(id, iL), I(id, iC), I(id, iR)};
+                Nbr n;
+                n.u[0] = X(ru, xL); n.w[0] = X(ru, FB + xL);
+                n.u[1] = X(ru, xC); n.w[1] = X(ru, FB + xC); n.g[1] = X(ru, 2 * FB + xC);
+                n.u[2] = X(ru, xR); n.w[2] = X(ru, FB + xR);
+                n.u[3] = X(rc, xL); n.w[3] = X(rc, FB + xL); n.g[3] = X(rc, 2 * FB + xL);
+                n.u[5] = X(rc, xR); n.w[5] = X(rc, FB + xR); n.g[5] = X(rc, 2 * FB + xR);
+                n.u[6] = X(rd, xL); n.w[6] = X(rd, FB + xL);
+                n.u[7] = X(rd, xC); n.w[7] = X(rd, FB + xC); n.g[7] = X(rd, 2 * FB + xC);
+                n.u[8] = X(rd, xR); n.w[8] = X(rd, FB + xR);
+                double u, w, gm;
+#ifdef SW_EXP_NOMATH   // experiment build: the LDS reads of the stage, but (almost) no arithmetic
+                u = n.u[0] + n.u[1] + n.u[2] + n.u[3] + n.u[5] + n.u[6] + n.u[7] + n.u[8] + imv[0] + imv[1] + imv[2];
+                w = n.w[0] + n.w[1] + n.w[2] + n.w[3] + n.w[5] + n.w[6] + n.w[7] + n.w[8] + imv[3] + imv[4] + imv[5];
+                gm = n.g[1] + n.g[3] + n.g[5] + n.g[7] + imv[6] + imv[7] + imv[8] + b0 + b1 + b2;
+#else
+                if (EDGE) {
+                    const double sUL = (oU && oL) ? 2.0 : 1.0, sUR = (oU && oR) ? 2.0 : 1.0;
+                    const double sDL = (oD && oL) ? 2.0 : 1.0, sDR = (oD && oR) ? 2.0 : 1.0;
+                    gs0_point<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, b0, b1, b2, u, w, gm);
+                } else {
+                    gs0_point<false>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, b0, b1, b2, u, w, gm);
+                }
+#endif
+                char* row = ring + rowC + xC;
+                *reinterpret_cast<VT*>(row) = (VT)u;
+                *reinterpret_cast<VT*>(row + FB) = (VT)w;
+                *reinterpret_cast<VT*>(row + 2 * FB) = (VT)gm;
+            }
+        }
+#endif
+        // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
+        if (do_load) {
+            if (EC) {   // x + (P e)(pL, q) from the coarse ring - after the stage, so that the row loads issued in (2) have had
+                        // the whole stage to arrive (interpolating right after the loads serialised load latency and stage)
+                const bool rowok = EDGE ? (pL >= 0 && pL < ni) : true;
+                if (rowok && ccv) {
+                    const int cp = pL >> 1;
+                    const bool ipi = (pL & 1) && (cp + 1 < nci);
+                    const double wi0 = ipi ? 0.5 : 1.0, wj0 = ipj ? 0.5 : 1.0;
+                    const VT* c0 = cr + cr_slot(cp) * 3 * CRW + ilcq;
+                    const VT* c1 = cr + cr_slot(cp + 1) * 3 * CRW + ilcq;
+                    VT* lxp[3] = {&lx0, &lx1, &lx2};
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        double v = wi0 * wj0 * (double)c0[f * CRW];
+                        if (ipj) v += wi0 * 0.5 * (double)c0[f * CRW + 1];
+                        if (ipi) {
+                            v += 0.5 * wj0 * (double)c1[f * CRW];
+                            if (ipj) v += 0.25 * (double)c1[f * CRW + 1];
+                        }
+                        *lxp[f] = (VT)((double)*lxp[f] + v);
+                    }
+                }
+            }
+            char* lrow = ring + ringR;
+            *reinterpret_cast<VT*>(lrow + clds) = lx0;
+            *reinterpret_cast<VT*>(lrow + FB + clds) = lx1;
+            *reinterpret_cast<VT*>(lrow + 2 * FB + clds) = lx2;
+            *reinterpret_cast<double*>(lrow + ilds0) = li0;
+            if (ccol < 2) *reinterpret_cast<double*>(lrow + ilds1) = li1;
+            if (EC) { if (cr_on) cr[(cr_slot(knew) * 3 + crf) * CRW + crc] = crv; }
+        }
+    };
+
+    for (int s = -2; s <= s_end; ++s) {
+        const int e = 2 * s;
+        if (e >= e_lo && e <= e_hi) step(std::false_type{}, e);
+        else step(std::true_type{}, e);
+        ringR = wrapB(ringR + 2 * RSB);
+        rowC = wrapB(rowC + 2 * RSB);
+        gL += 2 * (long long)nj; gW += 2 * (long long)nj; gB += 2 * (long long)nj; gI += 2 * (long long)Nj;
+        __syncthreads();
+    }
+}
+
+// ==========================================================================================
 // k_stream_apply0: level-0 operator application y = A x (MODE 0) or y = b - A x (MODE 1), matrix-free,
 // streaming over rows through an LDS ring (every array is read once, coalesced; the 9-point neighbourhood and
 // the 3x3 image neighbourhood come from LDS).  A block owns a 128-column aligned strip (+1 halo column each
@@ -1754,7 +2158,12 @@ __global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, i
 // slot 0 = sum y * dotvec (or y * y if dotvec == nullptr and want_yy), slot 1 = sum y * y (dotvec && want_yy);
 // per-block partials are written at index blockIdx.y * gridDim.x + blockIdx.x (deterministic two-stage sum).
 // ==========================================================================================
-constexpr int AP_OUT = 128, AP_W = 132, AP_RING = 8, AP_THREADS = 256;
+constexpr int AP_OUT = 128, AP_W = 132, AP_THREADS = 256;
+// Ring depth: a step loads rows r + 3, r + 4 while rows r - 1 .. r + 2 are read, i.e. six live rows (the fused
+// residual + restriction kernel likewise keeps residual rows 2s - 4 .. 2s + 1).  Six slots instead of the next power of
+// two keep that kernel at 43.8 KB of LDS = 3 workgroups per CU (8 slots: 58 KB = 2 per CU, 2.9 TB/s).
+constexpr int AP_RING = 6;
+__device__ __forceinline__ int ap_slot(int row) { return (row + 64 * AP_RING) % AP_RING; }   // row >= -64 * AP_RING
 
 template <int MODE, typename XT, typename BT, typename YT>
 __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
@@ -1808,8 +2217,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
         const int rc = r + half, p = p0 + rc;
         if (s >= 0 && rc < TI && p < ni && col_ok) {
             const bool oU = p - 1 < 0, oD = p + 1 >= ni;
-            const int sU = ((rc - 1) + AP_RING) & (AP_RING - 1), sC = (rc + AP_RING) & (AP_RING - 1),
-                      sD = ((rc + 1) + AP_RING) & (AP_RING - 1);
+            const int sU = ap_slot(rc - 1), sC = ap_slot(rc), sD = ap_slot(rc + 1);
             const double* i0 = im + sU * AP_W;
             const double* i1 = im + sC * AP_W;
             const double* i2 = im + sD * AP_W;
@@ -1862,7 +2270,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
         }
         // ---- loaded row -> LDS ring
         if (rl <= TI) {
-            const int sl = (rl + AP_RING) & (AP_RING - 1);
+            const int sl = ap_slot(rl);
             XT* xr = xs + sl * 3 * AP_W;
             xr[col + 1] = l0; xr[AP_W + col + 1] = l1; xr[2 * AP_W + col + 1] = l2;
             if (col == 0 || col == 127) {
@@ -1945,7 +2353,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
                     const int fp = 2 * cp + di;
                     if (fp < 0 || fp >= ni) continue;
                     const double wi = pweight(fp, cp, nci);
-                    const double* row = rs + (((2 * k + 1 + di) & (AP_RING - 1)) * 3 + ef) * 128;
+                    const double* row = rs + (ap_slot(2 * k + 1 + di) * 3 + ef) * 128;
 #pragma unroll
                     for (int dj = -1; dj <= 1; ++dj) {
                         const int fq = 2 * ecq + dj;
@@ -1981,8 +2389,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
             double y0 = 0.0, y1 = 0.0, y2 = 0.0;
             if (p >= 0 && p < ni && col_ok) {
                 const bool oU = p - 1 < 0, oD = p + 1 >= ni;
-                const int sU = ((rc - 1) + AP_RING) & (AP_RING - 1), sC = (rc + AP_RING) & (AP_RING - 1),
-                          sD = ((rc + 1) + AP_RING) & (AP_RING - 1);
+                const int sU = ap_slot(rc - 1), sC = ap_slot(rc), sD = ap_slot(rc + 1);
                 const double* i0 = im + sU * AP_W;
                 const double* i1 = im + sC * AP_W;
                 const double* i2 = im + sD * AP_W;
@@ -2021,12 +2428,12 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
                 y1 = (double)b[off + npts + idx] - y1;
                 y2 = (double)b[off + 2 * npts + idx] - y2;
             }
-            double* rr = rs + ((rc & (AP_RING - 1)) * 3) * 128 + col;
+            double* rr = rs + (ap_slot(rc) * 3) * 128 + col;
             rr[0] = y0; rr[128] = y1; rr[256] = y2;
         }
         // ---- loaded row -> LDS ring
         if (need) {
-            const int sl = (rl + AP_RING) & (AP_RING - 1);
+            const int sl = ap_slot(rl);
             XT* xr = xs + sl * 3 * AP_W;
             xr[col + 1] = l0; xr[AP_W + col + 1] = l1; xr[2 * AP_W + col + 1] = l2;
             if (col == 0 || col == 127) {
@@ -2069,6 +2476,205 @@ __global__ __launch_bounds__(NT) void k_blur1d(const double* __restrict__ in, do
         acc += (a + b) * w[k + radius];
     }
     out[(size_t)f * Ni * Nj + (size_t)i * Nj + j] = acc;
+}
+
+// ==========================================================================================
+// k_tail_cycle: the coarse tail of the multigrid cycle in ONE launch, vectors resident in LDS.
+//
+// Levels whose whole grid fits one workgroup (<= 1024 points, i.e. 32 x 32 and coarser: three to four levels plus the
+// dense coarsest solve) are latency-bound: every sweep / residual / transfer is a launch of a few microseconds that
+// moves a few kilobytes per pair.  One workgroup per frame pair runs the whole sub-cycle instead: the level's
+// x (with a zero halo), b and a residual scratch live in LDS (float64, ~90 KB for 32^2 + 16^2 + 8^2 + 4^2), only the
+// Galerkin stencils are streamed (colour-split planes: consecutive threads read consecutive elements; 436 KB per pair,
+// i.e. they stay in L2 / the Infinity Cache between visits), and the only HBM traffic per visit is the right-hand side
+// in and the correction out.  The host compiles the cycle shape (V or one-level W, sweep counts) into a short list of
+// operations, so the kernel computes exactly what the per-level launches compute, in the same order.
+// ==========================================================================================
+constexpr int TAIL_THREADS = 256;
+constexpr int TAIL_MAX_LEVELS = 8;
+constexpr int TAIL_MAX_OPS = 160;
+constexpr int TAIL_MAX_PTS = 1024;    // points of the largest tail level
+constexpr int TAIL_MAX_SUB = 256;     // points per colour class of the largest tail level (= threads)
+enum TailOpCode { T_SMOOTH = 0, T_RESTRICT = 1, T_COARSE = 2, T_PROLONG = 3 };
+
+struct TailLevel {
+    int ni, nj;
+    int hj;                      // (nj + 1) / 2: row length of a colour sub-plane
+    int sub;                     // elements of a colour sub-plane ((ni + 1) / 2 * hj)
+    unsigned long long plane;    // CLay(ni, nj).plane
+    const void* C;               // stencil [pair][81][plane]; nullptr on the dense coarsest level
+    int xo, bo;                  // LDS offsets (in doubles) of x (3 x (ni + 2) x (nj + 2), zero halo) and b (3 x ni x nj)
+};
+struct TailArgs {
+    int nl;                      // tail levels; level nl - 1 is the coarsest (dense inverse)
+    int n_ops;
+    int ro;                      // LDS offset of the residual scratch (3 x points of tail level 0)
+    int nd;                      // unknowns of the coarsest level
+    const double* invT;          // [pair][nd][nd] transposed inverse
+    TailLevel L[TAIL_MAX_LEVELS];
+    // op_arg of T_SMOOTH: bit 0 = start from zero, bit 1 = reverse colour order, bits 2.. = number of sweeps
+    unsigned char op[TAIL_MAX_OPS], op_level[TAIL_MAX_OPS], op_arg[TAIL_MAX_OPS];
+};
+
+// one colour of a block-GS sweep (UPDATE) or of the residual r = b - A x (!UPDATE) on an LDS-resident level
+template <typename CT, bool UPDATE>
+__device__ __forceinline__ void tail_colour(const TailLevel& lv, const typename CoefFmt<CT>::word_t* __restrict__ Cp,
+                                            double* lds, int ro, int c) {
+    const int t = threadIdx.x;
+    const int pp = t / lv.hj, qq = t - pp * lv.hj;
+    const int p = 2 * pp + (c >> 1), q = 2 * qq + (c & 1);
+    if (t >= lv.sub || p >= lv.ni || q >= lv.nj) return;
+    const int W2 = lv.nj + 2, fs = (lv.ni + 2) * W2, npts = lv.ni * lv.nj;
+    CoefSet<CT> cf;
+    cf.load(Cp + (size_t)c * lv.sub + t, lv.plane);
+    double* xc = lds + lv.xo + (p + 1) * W2 + (q + 1);
+    double y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            if (UPDATE && a == 1 && bb == 1) continue;
+            const double* xn = xc + (a - 1) * W2 + (bb - 1);
+            const double xu = xn[0], xw = xn[fs], xg = xn[2 * fs];
+            const int t0 = (a * 3 + bb) * 9;
+            y0 += cf.get(t0 + 0) * xu + cf.get(t0 + 1) * xw + cf.get(t0 + 2) * xg;
+            y1 += cf.get(t0 + 3) * xu + cf.get(t0 + 4) * xw + cf.get(t0 + 5) * xg;
+            y2 += cf.get(t0 + 6) * xu + cf.get(t0 + 7) * xw + cf.get(t0 + 8) * xg;
+        }
+    }
+    const double* bp = lds + lv.bo + p * lv.nj + q;
+    if (UPDATE) {
+        double D[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) D[k] = cf.get(36 + k);
+        double u, w, g;
+        solve3(D, bp[0] - y0, bp[npts] - y1, bp[2 * npts] - y2, u, w, g);
+        xc[0] = u; xc[fs] = w; xc[2 * fs] = g;
+    } else {
+        double* rp = lds + ro + p * lv.nj + q;
+        rp[0] = bp[0] - y0; rp[npts] = bp[npts] - y1; rp[2 * npts] = bp[2 * npts] - y2;
+    }
+}
+
+template <typename CT, typename VT>
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail_cycle(TailArgs A, const VT* __restrict__ b_top, VT* __restrict__ x_top,
+                                                             int from_zero, const int* __restrict__ active) {
+    extern __shared__ double tl_lds[];
+    double* lds = tl_lds;
+    const int pair = blockIdx.x;
+    if (active && !active[pair]) return;
+    const int tid = threadIdx.x;
+    // ---- load: b of the top tail level, x (or zeros), zero halos of every level
+    {
+        const TailLevel& l0 = A.L[0];
+        const int npts = l0.ni * l0.nj, W2 = l0.nj + 2, fs = (l0.ni + 2) * W2;
+        for (int l = 0; l < A.nl; ++l) {
+            const TailLevel& lv = A.L[l];
+            const int n = 3 * (lv.ni + 2) * (lv.nj + 2);
+            for (int i = tid; i < n; i += TAIL_THREADS) lds[lv.xo + i] = 0.0;
+        }
+        __syncthreads();
+        const VT* bg = b_top + (size_t)pair * 3 * npts;
+        const VT* xg = x_top + (size_t)pair * 3 * npts;
+        for (int i = tid; i < 3 * npts; i += TAIL_THREADS) {
+            lds[l0.bo + i] = (double)bg[i];
+            if (!from_zero) {
+                const int f = i / npts, r = i - f * npts, p = r / l0.nj, q = r - p * l0.nj;
+                lds[l0.xo + f * fs + (p + 1) * W2 + (q + 1)] = (double)xg[i];
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = 0; o < A.n_ops; ++o) {
+        const int code = A.op[o], l = A.op_level[o], arg = A.op_arg[o];
+        const TailLevel& lv = A.L[l];
+        const typename CoefFmt<CT>::word_t* Cp = (const typename CoefFmt<CT>::word_t*)lv.C + (size_t)pair * CoefFmt<CT>::PLANES * lv.plane;
+        if (code == T_SMOOTH) {
+            const int nu = arg >> 2;
+            const bool rev = (arg & 2) != 0;
+            if (arg & 1) {   // zero initial guess (the halo is zero already)
+                const int n = 3 * (lv.ni + 2) * (lv.nj + 2);
+                for (int i = tid; i < n; i += TAIL_THREADS) lds[lv.xo + i] = 0.0;
+                __syncthreads();
+            }
+            for (int sw = 0; sw < nu; ++sw)
+                for (int k = 0; k < 4; ++k) {
+                    tail_colour<CT, true>(lv, Cp, lds, A.ro, rev ? 3 - k : k);
+                    __syncthreads();
+                }
+        } else if (code == T_RESTRICT) {   // b_{l+1} = R (b_l - A_l x_l)
+            for (int k = 0; k < 4; ++k) tail_colour<CT, false>(lv, Cp, lds, A.ro, k);
+            __syncthreads();
+            const TailLevel& lc = A.L[l + 1];
+            const int nf = lv.ni * lv.nj, nc = lc.ni * lc.nj;
+            for (int i = tid; i < 3 * nc; i += TAIL_THREADS) {
+                const int f = i / nc, r = i - f * nc, cp = r / lc.nj, cq = r - cp * lc.nj;
+                const double* rf = lds + A.ro + f * nf;
+                double s = 0.0;
+#pragma unroll
+                for (int di = -1; di <= 1; ++di) {
+                    const int fp = 2 * cp + di;
+                    if (fp < 0 || fp >= lv.ni) continue;
+                    const double wi = pweight(fp, cp, lc.ni);
+#pragma unroll
+                    for (int dj = -1; dj <= 1; ++dj) {
+                        const int fq = 2 * cq + dj;
+                        if (fq < 0 || fq >= lv.nj) continue;
+                        s += wi * pweight(fq, cq, lc.nj) * rf[fp * lv.nj + fq];
+                    }
+                }
+                lds[lc.bo + i] = 0.25 * s;
+            }
+            __syncthreads();
+        } else if (code == T_COARSE) {     // x = A^-1 b with the stored dense inverse
+            const double* M = A.invT + (size_t)pair * A.nd * A.nd;
+            const int npts = lv.ni * lv.nj, W2 = lv.nj + 2, fs = (lv.ni + 2) * W2;
+            for (int i = tid; i < A.nd; i += TAIL_THREADS) {
+                double s = 0.0;
+                for (int j = 0; j < A.nd; ++j) s += M[(size_t)j * A.nd + i] * lds[lv.bo + j];
+                const int f = i / npts, r = i - f * npts, p = r / lv.nj, q = r - p * lv.nj;
+                lds[lv.xo + f * fs + (p + 1) * W2 + (q + 1)] = s;
+            }
+            __syncthreads();
+        } else {                            // T_PROLONG: x_l += P x_{l+1}
+            const TailLevel& lc = A.L[l + 1];
+            const int nf = lv.ni * lv.nj, W2 = lv.nj + 2, fs = (lv.ni + 2) * W2;
+            const int W2c = lc.nj + 2, fsc = (lc.ni + 2) * W2c;
+            for (int i = tid; i < 3 * nf; i += TAIL_THREADS) {
+                const int f = i / nf, r = i - f * nf, fp = r / lv.nj, fq = r - fp * lv.nj;
+                const double* xcs = lds + lc.xo + f * fsc;
+                const int cp0 = fp >> 1, cq0 = fq >> 1;
+                double s = 0.0;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int cp = cp0 + a;
+                    if (cp >= lc.ni) continue;
+                    const double wi = pweight(fp, cp, lc.ni);
+                    if (wi == 0.0) continue;
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int cq = cq0 + bb;
+                        if (cq >= lc.nj) continue;
+                        const double w = wi * pweight(fq, cq, lc.nj);
+                        if (w == 0.0) continue;
+                        s += w * xcs[(cp + 1) * W2c + (cq + 1)];
+                    }
+                }
+                lds[lv.xo + f * fs + (fp + 1) * W2 + (fq + 1)] += s;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- store the correction of the top tail level
+    {
+        const TailLevel& l0 = A.L[0];
+        const int npts = l0.ni * l0.nj, W2 = l0.nj + 2, fs = (l0.ni + 2) * W2;
+        VT* xg = x_top + (size_t)pair * 3 * npts;
+        for (int i = tid; i < 3 * npts; i += TAIL_THREADS) {
+            const int f = i / npts, r = i - f * npts, p = r / l0.nj, q = r - p * l0.nj;
+            xg[i] = (VT)lds[l0.xo + f * fs + (p + 1) * W2 + (q + 1)];
+        }
+    }
 }
 
 // ==========================================================================================

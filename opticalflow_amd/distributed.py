@@ -49,7 +49,7 @@ def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=No
     [rank][pair] = natural order).  ``output="numpy"`` (default, the reference's contract OF.py:1193-1197) copies the
     re-assembled stacks to host arrays; ``output="torch"`` leaves every array on the device.
 
-    ``solve_fn(sub_movie, **kwargs) -> dict`` replaces the per-shard solver (CPU tests inject the oracle and run the
+    ``solve_fn(sub_movie, **kwargs) -> dict`` replaces the per-shard solver (the CPU tests inject a host solver and run the
     same code over gloo).
     """
     import torch

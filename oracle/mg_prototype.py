@@ -13,7 +13,7 @@ Algorithm:
     restriction R = P^T / 4, Galerkin coarse operators ``A_c = R A P`` (again 9-point),
     smoother = 4-colour 3x3-block Gauss-Seidel (colour = 2 (p mod 2) + (q mod 2), order 0,1,2,3
     before and 3,2,1,0 after the coarse-grid correction), dense solve on the coarsest grid
-    (``max(n) <= 9``);
+    (``max(n) <= 5``);
   * outer iteration: right-preconditioned BiCGStab (the reference's KSP type, OF.py:1081) with one
     V-cycle as preconditioner; stop when ``||b - A x||_2 <= rtol ||b||_2`` (OF.py:1120,1126).
 """
@@ -24,7 +24,7 @@ import scipy.sparse as sp
 
 from . import vof_oracle as orc
 
-COARSEST_MAX = 9
+COARSEST_MAX = 5
 
 
 # ------------------------------------------------------------------ fine-level folded stencil
