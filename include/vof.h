@@ -99,6 +99,8 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *   VOF_FUSE_RESTRICT=0        level 0: separate residual and restriction kernels
  *   VOF_FUSE_PROLONG=0         level 0: separate prolongation kernel instead of interpolating inside the first post-sweep
  *   VOF_SWEEP0=0               level 0: the generic fused sweep kernel instead of the dedicated k_sweep0
+ *   VOF_SWEEP0M=0|1            level 0, float64 vectors: 0 = the 4-wave kernel k_sweep0; 1 = k_sweep0m with one sweep per pass
+ *                              (default: k_sweep0m, two sweeps per pass)
  *   VOF_COARSEST_MAX=3..9      coarsen until max(n_i, n_j) <= this (default 5); changes the hierarchy depth, hence iteration counts
  *   VOF_COARSE_TAIL=0          levels whose whole grid fits one workgroup: one launch per operation instead of the fused
  *                              LDS-resident coarse-tail kernel */
@@ -206,6 +208,8 @@ int vof_debug_apply(vof_ctx* ctx, int level, const double* x_host, double* y_hos
 int vof_debug_gs(vof_ctx* ctx, int level, double* x_host, const double* b_host, int colour);
 /* one full fused 4-colour sweep (reverse: colour order 3,2,1,0; from_zero: ignore x, start from 0) */
 int vof_debug_sweep(vof_ctx* ctx, int level, double* x_host, const double* b_host, int reverse, int from_zero);
+/* nu full sweeps as the multigrid cycle runs them (on level 0: the passes of k_sweep0m, two sweeps each) */
+int vof_debug_smooth(vof_ctx* ctx, int level, double* x_host, const double* b_host, int nu, int reverse, int from_zero);
 int vof_debug_restrict(vof_ctx* ctx, int level, const double* fine_host, double* coarse_host);
 int vof_debug_prolong_add(vof_ctx* ctx, int level, double* fine_host, const double* coarse_host);
 int vof_debug_stencil(vof_ctx* ctx, int level, double* c_host); /* [pair][81][n_i][n_j], level >= 1 */

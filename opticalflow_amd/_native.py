@@ -84,6 +84,7 @@ SIGNATURES = {
     "vof_debug_apply": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "vof_debug_gs": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int]),
     "vof_debug_sweep": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
+    "vof_debug_smooth": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "vof_set_fused_sweeps": (C.c_int, [_vp, C.c_int]),
     "vof_debug_restrict": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "vof_debug_prolong_add": (C.c_int, [_vp, C.c_int, _vp, _vp]),
@@ -357,6 +358,12 @@ class Solver:
         x = np.array(x, dtype=np.float64, copy=True).reshape(self._vec(level))
         b = np.ascontiguousarray(b, dtype=np.float64).reshape(self._vec(level))
         self._check(self.lib.vof_debug_sweep(self.h, level, _ptr(x), _ptr(b), int(reverse), int(from_zero)), "debug_sweep")
+        return x
+
+    def debug_smooth(self, level, x, b, nu, reverse=False, from_zero=False):
+        x = np.array(x, dtype=np.float64, copy=True).reshape(self._vec(level))
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(self._vec(level))
+        self._check(self.lib.vof_debug_smooth(self.h, level, _ptr(x), _ptr(b), int(nu), int(reverse), int(from_zero)), "debug_smooth")
         return x
 
     def set_fused_sweeps(self, on=True):

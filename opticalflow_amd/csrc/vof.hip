@@ -112,6 +112,8 @@ struct vof_ctx {
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     bool sweep0 = true;         // level 0: dedicated k_sweep0 kernel (VOF_SWEEP0=0: the generic k_sweep<SweepFine, GeoA>)
+    bool sweep0m = true;        // level 0, float64 vectors, even n_j: k_sweep0m (VOF_SWEEP0M=0: k_sweep0)
+    bool sweep0m_pairs = true;  // ... two sweeps per pass (VOF_SWEEP0M=1: one sweep per pass)
     bool tail_enabled = true;   // fused LDS-resident coarse-tail kernel (VOF_COARSE_TAIL=0: one launch per operation)
     int tail_first = -1;        // first level of the tail (-1: no tail for this grid)
     size_t tail_lds = 0;        // dynamic LDS bytes of k_tail_cycle
@@ -369,13 +371,46 @@ void coarse_solve_t(vof_ctx* c, const VT* r, VT* e, int np, const int* active) {
     k_coarse_solve<VT><<<np, 256, c->nd * sizeof(double), c->stream>>>(c->invT, c->nd, r, e, active);
 }
 
+// k_sweep0m (merged colours, 16-byte accesses, up to two sweeps per pass) needs float64 vectors and an even row length
+inline bool sweep0m_usable(const vof_ctx* c) {
+    return c->sweep0m && c->sweep0 && c->fused && !c->geo_b_fine && !c->vfloat && (c->L[0].nj % 2 == 0) && c->L[0].C == nullptr;
+}
+
 // One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
+// nsweeps = 2 (level 0, k_sweep0m only): two consecutive sweeps in one pass.
 template <typename VT>
 void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
-                   const int* active, const VT* ecoarse = nullptr) {
+                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1) {
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
     int rows = lv.ni + po;
+    if constexpr (std::is_same<VT, double>::value) {
+        if (l == 0 && lv.C == nullptr && sweep0m_usable(c)) {
+            // k_sweep0m: merged colours, 16-byte accesses, `nsweeps` (1 or 2) sweeps per pass; strips are not shifted by po
+            const int NSW = nsweeps >= 2 ? 2 : 1;
+            const int out = S0_W - 8 * NSW;
+            const int nx = (lv.nj + out - 1) / out;
+            const int TI = pick_band_height(rows, nx, c->cur_units);
+            const int ny = (rows + TI - 1) / TI;
+            dim3 g((unsigned)nx * ny * np, 1, 1);
+            int nci = 0, ncj = 0;
+            double ebytes = 0.0;
+            if (ecoarse) { nci = c->L[1].ni; ncj = c->L[1].nj; ebytes = 24.0 * c->L[1].npts; }
+            // algorithmic bytes of the pass: I + b(3) + x(3) in, x(3) out (+ coarse e), whatever the number of fused sweeps
+            Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * 8.0) * lv.npts + ebytes);
+            Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, c->prm.reference_quirks, c->pp};
+            const size_t lds = (size_t)(6 * NSW + 2) * s0_row_bytes(8) + (ecoarse ? (size_t)9 * (S0_W / 2 + 2) * 8 : 0);
+#define VOF_LAUNCH_S0M(NS_)                                                                                                        \
+            do {                                                                                                                    \
+                if (ecoarse) k_sweep0m<NS_, true, false><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
+                else if (!x_in) k_sweep0m<NS_, false, true><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
+                else k_sweep0m<NS_, false, false><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
+            } while (0)
+            if (NSW == 2) VOF_LAUNCH_S0M(2); else VOF_LAUNCH_S0M(1);
+#undef VOF_LAUNCH_S0M
+            return;
+        }
+    }
     const bool geoB = (l > 0) ? c->geo_b_stored : c->geo_b_fine;
     const int out = geoB ? GeoB::OUT : GeoA::OUT, W = geoB ? GeoB::W : GeoA::W, IW = geoB ? GeoB::IW : GeoA::IW;
     const int TI = pick_band_height(rows, (lv.nj + (geoB ? 0 : po) + out - 1) / out, c->cur_units);
@@ -438,11 +473,17 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
                 gs_colour(c, l, (double*)x, (const double*)b, reverse ? 3 - k : k, np, active);
         return x;
     }
-    // out-of-place fused sweeps: choose the first destination so that the last sweep writes into x
+    // out-of-place fused sweeps: choose the first destination so that the last pass writes into x.  On level 0 a pass of
+    // k_sweep0m performs two sweeps (temporal blocking): nu sweeps = ceil(nu / 2) passes over the data.
+    const bool two = l == 0 && std::is_same<VT, double>::value && sweep0m_usable(c) && c->sweep0m_pairs;
+    const int npass = two ? (nu + 1) / 2 : nu;
     const VT* src = from_zero ? nullptr : x;
-    VT* dst = (from_zero && (nu % 2 == 1)) ? x : tmp;
-    for (int s = 0; s < nu; ++s) {
-        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr);
+    VT* dst = (from_zero && (npass % 2 == 1)) ? x : tmp;
+    int left = nu;
+    for (int s = 0; s < npass; ++s) {
+        const int ns = two ? std::min(2, left) : 1;
+        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns);
+        left -= ns;
         src = dst;
         dst = (dst == x) ? tmp : x;
     }
@@ -531,11 +572,18 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
             ec = vcycle_t<VT>(c, l + 1, ec, other, (const VT*)nx.b, np, active, false);
         }
     }
-    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/l > 0);
+    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/true);
 }
 
-void vcycle(vof_ctx* c, void* x, const void* b, int np, const int* active) {
-    VDISPATCH(c, vcycle_t<VT>(c, 0, (VT*)x, (VT*)c->L[0].x2, (const VT*)b, np, active));
+// One cycle M b -> *xslot (c->ky or c->kz).  The out-of-place sweeps may leave the result in the level-0 ping-pong partner
+// instead (an odd number of passes); the two buffers then trade places - a pointer swap instead of a copy of the vector.
+void vcycle(vof_ctx* c, double** xslot, const void* b, int np, const int* active) {
+    void* res = nullptr;
+    VDISPATCH(c, res = (void*)vcycle_t<VT>(c, 0, (VT*)*xslot, (VT*)c->L[0].x2, (const VT*)b, np, active));
+    if (res != (void*)*xslot) {
+        c->L[0].x2 = (void*)*xslot;
+        *xslot = (double*)res;
+    }
 }
 
 // Build the Galerkin hierarchy and the coarsest-level dense inverse for the current batch.
@@ -691,7 +739,7 @@ int gmres_phase(vof_ctx* c, int np, int* handed_over) {
         int jdone = 0;
         for (int j = 0; j < m; ++j) {
             const int* act = c->active;
-            vcycle(c, c->ky, V + (size_t)j * vstride, np, act);             // z = M v_j
+            vcycle(c, &c->ky, V + (size_t)j * vstride, np, act);             // z = M v_j
             krylov_apply(c, c->ky, w, np, act);                              // w = A z
             for (int pass = 0; pass < 2; ++pass) {                           // classical Gram-Schmidt, twice
                 for (int i0 = 0; i0 <= j; i0 += GM_NV) {
@@ -726,7 +774,7 @@ int gmres_phase(vof_ctx* c, int np, int* handed_over) {
             k_gm_axpy<<<rg, RBLK, 0, s>>>(V + (size_t)i0 * vstride, vstride, i0, cnt, c->gm_state, coef_y, 1.0,
                                           i0 ? c->kp : nullptr, c->kp, len, c->gm_cycle, 1, nullptr);
         }
-        vcycle(c, c->ky, c->kp, np, c->gm_cycle);
+        vcycle(c, &c->ky, c->kp, np, c->gm_cycle);
         { Prof p(c, VOF_K_VECTOR, 0, 24.0 * len); k_gm_xpy<<<rg, RBLK, 0, s>>>(c->kx, c->ky, len, c->gm_cycle); }
         HIPCHK(hipGetLastError());
     }
@@ -793,7 +841,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         const double vsz = c->vfloat ? 4.0 : 8.0;
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));   // p = r + beta (p - omega v)
           VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
-        vcycle(c, c->ky, vrhs_p, np, act);                             // y = M p
+        vcycle(c, &c->ky, vrhs_p, np, act);                             // y = M p
         int nb1 = krylov_apply(c, c->ky, c->kv, np, act, c->krh, 0);   // v = A y, fused (r^, v)
         if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, nb1, c->active, P.rtol, P.max_iterations); }
@@ -803,7 +851,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         { Prof p(c, VOF_K_VECTOR, 0);                                  // pairs done at the half step: x += alpha y
           VDISPATCH(c, (k_fix_half<VT><<<dim3(64, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, len, c->sc)));
           k_clear_half<<<(np + 255) / 256, 256, 0, s>>>(c->sc, np); }
-        vcycle(c, c->kz, vrhs_s, np, act);                             // z = M s
+        vcycle(c, &c->kz, vrhs_s, np, act);                             // z = M s
         int nb2 = krylov_apply(c, c->kz, c->kt, np, act, c->kr, 1);    // t = A z, fused (t, s) and (t, t)
         if (!nb2) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); nb2 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, nb2, c->active, P.rtol, P.max_iterations); }
@@ -1022,6 +1070,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
+    if (const char* e = getenv("VOF_SWEEP0M")) { c->sweep0m = e[0] != '0'; c->sweep0m_pairs = e[0] != '0' && e[0] != '1'; }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
     c->L.push_back(l0);
@@ -1779,6 +1828,17 @@ int vof_debug_sweep(vof_ctx* c, int level, double* x_host, const double* b_host,
     return dbg_down(c, x_host, c->kt, n);
 }
 
+int vof_debug_smooth(vof_ctx* c, int level, double* x_host, const double* b_host, int nu, int reverse, int from_zero) {
+    DBG_LEVEL(level)
+    if (level + 1 >= (int)c->L.size()) { c->err = "coarsest level has no smoother"; return -1; }
+    if (nu < 1) { c->err = "nu must be >= 1"; return -1; }
+    size_t n = nbytes / sizeof(double);
+    if (int rc = dbg_up(c, c->kp, x_host, n)) return rc;
+    if (int rc = dbg_up(c, c->kv, b_host, n)) return rc;
+    VDISPATCH(c, smooth_level_t<VT>(c, level, (VT*)c->kp, (VT*)c->kt, (const VT*)c->kv, nu, from_zero != 0, reverse != 0, c->npairs, nullptr));
+    return dbg_down(c, x_host, c->kp, n);
+}
+
 int vof_set_fused_sweeps(vof_ctx* c, int on) {
     if (!c) return -1;
     c->fused = on != 0;
@@ -1852,7 +1912,7 @@ int vof_debug_vcycle(vof_ctx* c, const double* r_host, double* e_host) {
     DBG_LEVEL(0)
     size_t n = nbytes / sizeof(double);
     if (int rc = dbg_up(c, c->kp, r_host, n)) return rc;
-    vcycle(c, c->ky, c->kp, c->npairs, nullptr);
+    vcycle(c, &c->ky, c->kp, c->npairs, nullptr);
     return dbg_down(c, e_host, c->ky, n);
 }
 

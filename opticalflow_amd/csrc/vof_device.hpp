@@ -1459,6 +1459,7 @@ struct SweepFine {
     const PairParam* pp;   // per-pair overrides (virtual pairs) or nullptr
     static constexpr bool kHasImage = true;
     static constexpr int kPrefetch = 0;   // no per-point coefficient planes
+    static constexpr int kMinWaves = 1;
     struct cset_t { __device__ __forceinline__ void clear() {} };
     __device__ __forceinline__ void prefetch(const SweepCols&, size_t, int, cset_t&) const {}
 
@@ -1513,6 +1514,13 @@ struct SweepStored {
 #else
     static constexpr int kPrefetch = sizeof(word_t) == 4 ? 1 : 0;
 #endif
+    // Register budget (launch bound): 2 waves per SIMD, i.e. no limit that forces spills.  Measured: forcing 128 VGPRs (4 waves
+    // per SIMD, 3 workgroups per CU) spills ~110 bytes per thread and halves the kernel's speed; the compiler's own choice
+    // (~154 registers for the packed bfloat16 format, 2 workgroups of 5 waves per CU) runs at 4.1 TB/s.
+#ifndef SW_STORED_MINWAVES
+#define SW_STORED_MINWAVES 2
+#endif
+    static constexpr int kMinWaves = sizeof(word_t) == 4 ? SW_STORED_MINWAVES : 2;
     typedef CoefSet<CT> cset_t;
     __device__ __forceinline__ void prefetch(const SweepCols& cc, size_t rowpart, int pair, cset_t& cf) const {
         cf.load(C + (size_t)pair * CoefFmt<CT>::PLANES * plane + rowpart + cc.cq, plane);
@@ -1576,7 +1584,7 @@ __device__ __forceinline__ SweepRows sweep_rows(const SweepGeom& g, int rr, int 
 // (which read each other's halo lines of x, b and of the coefficient planes) run on the same XCD at about the
 // same time and find those lines in its L2.  Pure speed: any placement gives the same result.
 template <class Pol, class G, typename VT>
-__global__ __launch_bounds__(G::THREADS) void k_sweep(Pol pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
+__global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
                                                const VT* __restrict__ x_in, VT* __restrict__ x_out,
                                                const VT* __restrict__ b, const int* __restrict__ active,
                                                const VT* __restrict__ ecoarse, int nci, int ncj) {
@@ -2144,6 +2152,328 @@ __global__ __launch_bounds__(S0_THREADS) void k_sweep0(Fine0 pol, int ni, int nj
         if (e >= e_lo && e <= e_hi) step(std::false_type{}, e);
         else step(std::true_type{}, e);
         ringR = wrapB(ringR + 2 * RSB);
+        rowC = wrapB(rowC + 2 * RSB);
+        gL += 2 * (long long)nj; gW += 2 * (long long)nj; gB += 2 * (long long)nj; gI += 2 * (long long)Nj;
+        __syncthreads();
+    }
+}
+
+// ==========================================================================================
+// k_sweep0m: NS (1 or 2) consecutive 4-colour sweeps of level 0 in ONE pass over the data, float64 vectors, nj even.
+//
+// Two ideas on top of k_sweep0:
+//  * Merged colours.  A wave owns whole rows of a strip: lane i holds the column pair (2i, 2i + 1).  The "even-row" wave E
+//    of a sweep updates colour 0 then colour 1 of relative row e, the "odd-row" wave O colours 2 then 3 of row e - 3 (its
+//    neighbours e - 4, e - 2 were finished by E one and two steps earlier).  Colour 1 needs the colour-0 values of the
+//    same row, which the same wave has just written to LDS - no workgroup barrier in between (LDS operations of a wave
+//    execute in order).  So a sweep needs 2 waves and an 8-row ring instead of 4 waves and 12 rows, and every global
+//    access is 16 bytes per lane: x rows, b rows, image rows and the stores move whole aligned 1 KB field rows per
+//    wave instruction (the 4-wave kernel moved 8 bytes per lane and read b with stride 2).
+//  * Temporal blocking.  With NS = 2 a second pair of waves runs the NEXT sweep six rows behind the first one on the
+//    same ring (14 rows): the two sweeps of a (2, 2) smoothing step read x, b, I once and write x once - 80 instead of
+//    160 bytes per pixel (56 instead of 136 for the pair "from zero + second pre-sweep", 86 instead of 166 with the
+//    interpolated coarse-grid correction).  Price: 8 instead of 4 halo columns per side (112 of 128 ring columns owned)
+//    and 3 more halo rows per band side; the arithmetic per byte doubles, still far from the FP64 ridge.
+// Same update function (gs0_point) and the same global colour order as the other level-0 smoothers: results are identical
+// bit for bit to NS launches of k_sweep0 / to the per-colour kernels.
+//
+// Schedule (relative rows, e = 2 s; sweep k = 0 .. NS-1; ring of R = 6 NS + 2 rows, slot = row mod R):
+//   loads: rows e + 2, e + 3      E_k: row e - 6k      O_k: row e - 3 - 6k      write-out: rows e - 6 NS, e - 6 NS + 1
+// Column validity after stage c' (0..3 in processing order) of sweep k: local columns [2 - po + c' + 4k, 126 - po - c' - 4k];
+// owned columns [4 NS, 128 - 4 NS).  Row ranges: E_k [-2 m, TI + 2 m], O_k [-2 m + 1, TI + 2 m - 1] with m = NS - 1 - k.
+// ==========================================================================================
+template <int NS> struct S0M {
+    static constexpr int THREADS = 128 * NS, NW = 2 * NS, R = 6 * NS + 2, HALO = 4 * NS, OUT = S0_W - 8 * NS;
+    static constexpr int RSB = 3 * S0_W * 8 + S0_IW * 8;   // ring row: 3 x 128 doubles of x, 132 doubles of image
+    static constexpr int CRW = S0_W / 2 + 2;               // coarse ring width
+};
+
+template <int NS, bool EC, bool FROM_ZERO>
+__global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
+                                                       const double* __restrict__ x_in, double* __restrict__ x_out,
+                                                       const double* __restrict__ b, const int* __restrict__ active,
+                                                       const double* __restrict__ ecoarse, int nci, int ncj) {
+    typedef S0M<NS> G;
+    constexpr int W = S0_W, IW = S0_IW, NW = G::NW, R = G::R, RSB = G::RSB, RINGB = R * RSB, CRW = G::CRW;
+    constexpr int FB = W * 8, XB = 3 * FB, HB = (W / 2) * 8, IHB = (IW / 2) * 8;   // field stride, image part, parity halves
+    extern __shared__ double sw_lds[];
+    char* ring = reinterpret_cast<char*>(sw_lds);
+    double* cr = reinterpret_cast<double*>(ring + RINGB);   // [3 slots][3 fields][CRW] (EC only)
+    const unsigned nblocks = (unsigned)nx * ny * nz;
+    unsigned lb = blockIdx.x;
+    if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
+    const int bx = lb % nx, by = (lb / nx) % ny;
+    const int pair = lb / (nx * ny);
+    if (active && !active[pair]) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = by * TI - po;                 // true row of relative row 0 (reverse order: rows shifted by one)
+    const int qs = bx * G::OUT - G::HALO;        // true column of local column 0 (even: 16-byte aligned pairs)
+    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const double* xin = FROM_ZERO ? nullptr : x_in + off;
+    double* xout = x_out + off;
+    const double* bp = b + off;
+    const size_t ncpts = (size_t)nci * ncj;
+    const double* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
+    double alpha = pol.alpha, beta = pol.beta;
+    int fidx = pair;
+    if (pol.pp) { alpha = pol.pp[pair].alpha; beta = pol.pp[pair].beta; fidx = pol.pp[pair].frame; }
+    const double* img = pol.frames + (size_t)fidx * pol.frame_stride;
+    const int Nj = pol.Nj, quirks = pol.quirks;
+    const double inv_g = 1.0 / (-1 - 4 * beta);
+
+    // ---- this wave's stage: sweep k, even-row (E) or odd-row (O) wave
+    const int sk = wave >> 1, odd = wave & 1;
+    const int soff = -6 * sk - 3 * odd;                       // row of the stage relative to e
+    const int m = NS - 1 - sk;
+    const int rr_lo = -2 * m + odd, rr_hi = TI + 2 * m - odd;
+    // lane <-> column pair (2 lane, 2 lane + 1); pair validity is all-or-nothing (qs and nj are even)
+    const int qpair = qs + 2 * lane;
+    const bool pair_ok = qpair >= 0 && qpair + 1 < nj;
+    const size_t qg = pair_ok ? (size_t)qpair : 0;
+    const int le = lane * 8, lo_ = HB + lane * 8;             // x ring: byte offsets of the even / odd column of the pair
+    // ---- row traffic items of this wave: x field-rows fr = wave, wave + NW, ... (fr = 3 * row + field), image row (6 + r) % NW
+    const bool ipair_ok = qpair >= 0 && qpair + 1 <= nj + 1;               // image columns qs + 2 lane, + 1 (full image)
+    const size_t iqg = ipair_ok ? (size_t)qpair : 0;
+    const int xq = qs + 2 * 64;                                            // image pair 64 (ring columns 128, 129): lane 0 only
+    const bool xpair_ok = lane == 0 && xq >= 0 && xq + 1 <= nj + 1;
+    const bool st_ok = pair_ok && lane >= G::HALO / 2 && lane < (W - G::HALO) / 2;   // owned column pairs
+    // ---- coarse-correction ring (EC): lane <-> coarse column cqs + lane (+ 64, 65 by lanes 0, 1), wave 0 loads it
+    const int cqs = qs >> 1;
+    auto cr_slot = [](int k) { return ((k % 3) + 3) % 3; };
+    if (EC) {   // prologue: the two coarse rows the first load-in step needs
+        if (wave == 0) {
+            const int k0 = (p0 - 2 * NS) >> 1;   // the first step loads fine rows p0 - 2 NS, p0 - 2 NS + 1: coarse rows k0, k0 + 1
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int k = k0 + d;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const int c0 = cqs + lane, c1 = cqs + 64 + lane;
+                    double v0 = 0.0, v1 = 0.0;
+                    if (k >= 0 && k < nci && c0 >= 0 && c0 < ncj) v0 = ec[(size_t)f * ncpts + (size_t)k * ncj + c0];
+                    if (lane < 2 && k >= 0 && k < nci && c1 >= 0 && c1 < ncj) v1 = ec[(size_t)f * ncpts + (size_t)k * ncj + c1];
+                    cr[(cr_slot(k) * 3 + f) * CRW + lane] = v0;
+                    if (lane < 2) cr[(cr_slot(k) * 3 + f) * CRW + 64 + lane] = v1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- running state (advanced by two rows per step); first step: e = -2 NS - 2 (loads rows -2 NS, -2 NS + 1)
+    const int s_first = -NS - 1, s_last = TI / 2 + 3 * NS - 1;
+    const int e0 = 2 * s_first;
+    auto wrapB = [](int t) { return t >= RINGB ? t - RINGB : t; };
+    auto slot_of = [](int row) { return ((row % R) + R) % R; };
+    int ringL = slot_of(e0 + 2) * RSB;                         // ring row of relative row e + 2 (row e + 3 follows, wrapped)
+    int rowC = slot_of(e0 + soff) * RSB;                       // ring row of the stage's row e + soff
+    long long gL = (long long)(p0 + e0 + 2) * nj;              // x row e + 2 (elements); e + 3 is one row further
+    long long gW = (long long)(p0 + e0 - 6 * NS) * nj;         // x row e - 6 NS being written out
+    long long gI = (long long)(p0 + e0 + 3) * Nj;              // full-image row of relative row e + 2
+    long long gB = (long long)(p0 + e0 + 2 + soff) * nj;       // b row of the stage's NEXT row
+    // steps in which every row any wave touches exists and is an interior row (no predicates, no ghost rows, no corners)
+    int e_lo = 6 * NS, e_hi = TI + 2 * NS - 4;
+    e_lo = max(e_lo, 6 * NS - p0);  e_hi = min(e_hi, ni - 4 - p0);                         // stores / loads inside the image
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) {
+        const int k2 = w2 >> 1, o2 = w2 & 1, of2 = -6 * k2 - 3 * o2, m2 = NS - 1 - k2;
+        const int lo2 = -2 * m2 + o2, hi2 = TI + 2 * m2 - o2;
+        e_lo = max(e_lo, max(lo2 - of2, 1 - p0 - of2));
+        e_hi = min(e_hi, min(hi2 - of2 - 2, ni - 3 - p0 - of2));
+    }
+    double2 bn0 = {0, 0}, bn1 = {0, 0}, bn2 = {0, 0};   // b of the stage's row for the NEXT step (prefetched)
+
+    auto step = [&](auto edge_tag, const int e) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const bool do_load = EDGE ? (e + 3 <= TI + 2 * NS - 1) : true;
+        // ---- (1) write-out and (2) loads: this wave's items
+        double2 lx[3] = {{0, 0}, {0, 0}, {0, 0}};   // at most 3 x items per wave (NW = 2); NW = 4: 2
+        double2 li = {0, 0}, lix = {0, 0};
+        constexpr int NIT = (6 + NW - 1) / NW;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int fr = wave + it * NW;            // 0..5: row = fr / 3, field = fr % 3
+            if (fr < 6) {
+                const int row = fr >= 3 ? 1 : 0, f = fr - 3 * row;
+                const int rofs = wrapB(ringL + row * RSB) + f * FB;
+                {   // write-out of relative row e - 6 NS + row
+                    const int rrW = e - 6 * NS + row;
+                    const bool rowok = EDGE ? (rrW >= 0 && rrW < TI && p0 + rrW >= 0 && p0 + rrW < ni) : true;
+                    if (rowok && st_ok) {
+                        double2 v;
+                        v.x = *reinterpret_cast<const double*>(ring + rofs + le);
+                        v.y = *reinterpret_cast<const double*>(ring + rofs + lo_);
+                        *reinterpret_cast<double2*>(xout + (size_t)f * npts + (gW + (long long)row * nj) + qg) = v;
+                    }
+                }
+                if (!FROM_ZERO) {
+                    const int pL = p0 + e + 2 + row;
+                    const bool rowok = EDGE ? (do_load && pL >= 0 && pL < ni) : true;
+                    if (rowok && pair_ok) lx[it] = *reinterpret_cast<const double2*>(xin + (size_t)f * npts + (gL + (long long)row * nj) + qg);
+                }
+            }
+        }
+        {   // image row of this wave: item 6 + r -> wave (6 + r) % NW
+            const int r = (wave + NW - (6 % NW)) % NW;     // r = 0 or 1 for the two waves that own an image row
+            if (r < 2) {
+                const int pI = p0 + e + 3 + r;             // full-image row
+                const bool rowok = EDGE ? (do_load && pI >= 0 && pI <= ni + 1) : true;
+                if (rowok) {
+                    const double* frow = img + gI + (long long)r * Nj;
+                    if (ipair_ok) li = *reinterpret_cast<const double2*>(frow + iqg);
+                    if (xpair_ok) lix = *reinterpret_cast<const double2*>(frow + xq);
+                }
+            }
+        }
+        double crv0 = 0.0, crv1 = 0.0, crw0 = 0.0, crw1 = 0.0, cru0 = 0.0, cru1 = 0.0;
+        const int knew = ((p0 + e + 4) >> 1) + 1;          // coarse row needed by the NEXT step
+        if (EC) {
+            if (wave == 0 && knew >= 0 && knew < nci) {
+                const int c0 = cqs + lane, c1 = cqs + 64 + lane;
+                const double* er = ec + (size_t)knew * ncj;
+                if (c0 >= 0 && c0 < ncj) { crv0 = er[c0]; crw0 = er[ncpts + c0]; cru0 = er[2 * ncpts + c0]; }
+                if (lane < 2 && c1 >= 0 && c1 < ncj) { crv1 = er[c1]; crw1 = er[ncpts + c1]; cru1 = er[2 * ncpts + c1]; }
+            }
+        }
+        // ---- (3) this step's b (prefetched during the previous step) and the prefetch for the next step
+        const double2 b0 = bn0, b1 = bn1, b2 = bn2;
+        {
+            const int rrn = e + 2 + soff;
+            const bool rowok = EDGE ? (rrn >= rr_lo && rrn <= rr_hi && p0 + rrn >= 0 && p0 + rrn < ni) : true;
+            if (rowok && pair_ok) {
+                const double* brow = bp + gB + qg;
+                bn0 = *reinterpret_cast<const double2*>(brow);
+                bn1 = *reinterpret_cast<const double2*>(brow + npts);
+                bn2 = *reinterpret_cast<const double2*>(brow + 2 * npts);
+            }
+        }
+        // ---- (4) the stage: two colours of relative row e + soff, first the columns of true parity po
+        {
+            const int rr = e + soff, p = p0 + rr;
+            const bool rowok = EDGE ? (rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) : true;
+            if (rowok) {
+                const int rowU = rowC >= RSB ? rowC - RSB : rowC + RINGB - RSB;
+                const int rowD = wrapB(rowC + RSB);
+                const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
+                const char* ru = ring + (oU ? rowD : rowU);   // ghost row -1 mirrors row 1, ghost row n mirrors row n - 2
+                const char* rc = ring + rowC;
+                const char* rd = ring + (oD ? rowU : rowD);
+                const char* iu = ring + rowU + XB;            // the image has real border rows: no folding
+                const char* ic = ring + rowC + XB;
+                const char* id = ring + rowD + XB;
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int par = ph ^ po;                  // column parity of this phase (po is block-uniform)
+                    const int cidx = 2 * odd + ph;            // colour in processing order
+                    const int lc = 2 * lane + par;
+                    const int q = qs + lc;
+                    // dependency cone: one column per colour and side; with po = 1 the first colour sits on odd columns
+                    const bool on = lc >= 2 - po + cidx + 4 * sk && lc <= W - 2 - po - cidx - 4 * sk && q >= 0 && q < nj;
+                    if (on) {
+                        // x ring byte offsets of columns q - 1, q, q + 1 (parity-split halves), ghost columns folded
+                        const int oCn = par ? lo_ : le;
+                        int oLn = par ? le : lo_ - 8, oRn = par ? le + 8 : lo_;
+                        const bool gl = q - 1 < 0, gr = q + 1 >= nj;
+                        { const int tl = oLn; if (gl) oLn = oRn; if (gr) oRn = tl; }   // ghost column -1 mirrors 1, n mirrors n - 2
+                        // image ring: columns lci = lc, lc + 1, lc + 2 (full-image column = q + 1 +- 1)
+                        const int i0 = par ? IHB + lane * 8 : lane * 8;              // lci = lc
+                        const int i1 = par ? (lane + 1) * 8 : IHB + lane * 8;        // lci = lc + 1
+                        const int i2 = par ? IHB + (lane + 1) * 8 : (lane + 1) * 8;  // lci = lc + 2
+                        auto X = [](const char* r, int o) { return *reinterpret_cast<const double*>(r + o); };
+                        const double imv[9] = {X(iu, i0), X(iu, i1), X(iu, i2), X(ic, i0), X(ic, i1), X(ic, i2), X(id, i0), X(id, i1), X(id, i2)};
+                        Nbr n;
+                        n.u[0] = X(ru, oLn); n.w[0] = X(ru, FB + oLn);
+                        n.u[1] = X(ru, oCn); n.w[1] = X(ru, FB + oCn); n.g[1] = X(ru, 2 * FB + oCn);
+                        n.u[2] = X(ru, oRn); n.w[2] = X(ru, FB + oRn);
+                        n.u[3] = X(rc, oLn); n.w[3] = X(rc, FB + oLn); n.g[3] = X(rc, 2 * FB + oLn);
+                        n.u[5] = X(rc, oRn); n.w[5] = X(rc, FB + oRn); n.g[5] = X(rc, 2 * FB + oRn);
+                        n.u[6] = X(rd, oLn); n.w[6] = X(rd, FB + oLn);
+                        n.u[7] = X(rd, oCn); n.w[7] = X(rd, FB + oCn); n.g[7] = X(rd, 2 * FB + oCn);
+                        n.u[8] = X(rd, oRn); n.w[8] = X(rd, FB + oRn);
+                        const double c0 = par ? b0.y : b0.x, c1 = par ? b1.y : b1.x, c2 = par ? b2.y : b2.x;
+                        double u, w, gm;
+                        if (EDGE) {
+                            const double sUL = (oU && gl) ? 2.0 : 1.0, sUR = (oU && gr) ? 2.0 : 1.0;
+                            const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
+                            gs0_point<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
+                        } else {
+                            gs0_point<false>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
+                        }
+                        char* row = ring + rowC + oCn;
+                        *reinterpret_cast<double*>(row) = u;
+                        *reinterpret_cast<double*>(row + FB) = w;
+                        *reinterpret_cast<double*>(row + 2 * FB) = gm;
+                    }
+                    // the second colour reads what the first one wrote (same wave: LDS operations execute in order; the
+                    // fence only keeps the compiler from moving the reads above the writes)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        // ---- (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
+        if (do_load) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int fr = wave + it * NW;
+                if (fr < 6) {
+                    const int row = fr >= 3 ? 1 : 0, f = fr - 3 * row;
+                    double2 v = lx[it];
+                    if (EC) {   // x + (P e)(pL, q): after the stage, so that the loads of (2) have had the stage to arrive
+                        const int pL = p0 + e + 2 + row;
+                        const bool rowok = EDGE ? (pL >= 0 && pL < ni) : true;
+                        if (rowok && pair_ok) {
+                            const int cp = pL >> 1;
+                            const bool ipi = (pL & 1) && (cp + 1 < nci);
+                            const bool ipj = (qpair >> 1) + 1 < ncj;          // the odd column has a right coarse neighbour
+                            const double* c0p = cr + (cr_slot(cp) * 3 + f) * CRW + lane;
+                            const double* c1p = cr + (cr_slot(cp + 1) * 3 + f) * CRW + lane;
+                            const double wi0 = ipi ? 0.5 : 1.0;
+                            // same terms in the same order as k_prolong_add: (cp, cq), (cp, cq + 1), (cp + 1, cq), (cp + 1, cq + 1)
+                            double ve = wi0 * c0p[0];                          // even column: on a coarse column
+                            double vo = (ipj ? wi0 * 0.5 : wi0) * c0p[0];
+                            if (ipj) vo += wi0 * 0.5 * c0p[1];
+                            if (ipi) {
+                                ve += 0.5 * c1p[0];
+                                vo += (ipj ? 0.25 : 0.5) * c1p[0];
+                                if (ipj) vo += 0.25 * c1p[1];
+                            }
+                            v.x += ve; v.y += vo;
+                        }
+                    }
+                    const int rofs = wrapB(ringL + row * RSB) + f * FB;
+                    *reinterpret_cast<double*>(ring + rofs + le) = v.x;
+                    *reinterpret_cast<double*>(ring + rofs + lo_) = v.y;
+                }
+            }
+            {
+                const int r = (wave + NW - (6 % NW)) % NW;
+                if (r < 2) {
+                    char* irow = ring + wrapB(ringL + r * RSB) + XB;
+                    *reinterpret_cast<double*>(irow + lane * 8) = li.x;
+                    *reinterpret_cast<double*>(irow + IHB + lane * 8) = li.y;
+                    if (lane == 0) {
+                        *reinterpret_cast<double*>(irow + 64 * 8) = lix.x;
+                        *reinterpret_cast<double*>(irow + IHB + 64 * 8) = lix.y;
+                    }
+                }
+            }
+            if (EC) {
+                if (wave == 0) {
+                    double* cs = cr + cr_slot(knew) * 3 * CRW;
+                    cs[lane] = crv0; cs[CRW + lane] = crw0; cs[2 * CRW + lane] = cru0;
+                    if (lane < 2) { cs[64 + lane] = crv1; cs[CRW + 64 + lane] = crw1; cs[2 * CRW + 64 + lane] = cru1; }
+                }
+            }
+        }
+    };
+
+    for (int s = s_first; s <= s_last; ++s) {
+        const int e = 2 * s;
+        if (e >= e_lo && e <= e_hi) step(std::false_type{}, e);
+        else step(std::true_type{}, e);
+        ringL = wrapB(ringL + 2 * RSB);
         rowC = wrapB(rowC + 2 * RSB);
         gL += 2 * (long long)nj; gW += 2 * (long long)nj; gB += 2 * (long long)nj; gI += 2 * (long long)Nj;
         __syncthreads();

@@ -1,5 +1,5 @@
-"""Fixed-work timing of the level-0 sweep kernel (vof_bench_sweeps_dev): n sweeps on P pairs, HIP-event time per launch.
-usage: python scripts/gpu_sweep_micro.py [pairs] [sweeps] ; VOF_LIB selects an alternative build."""
+"""Fixed-work timing of the level-0 smoother (vof_bench_sweeps_dev): n sweeps on P pairs, HIP-event time per launch.
+usage: python scripts/gpu_sweep_micro.py [pairs] [sweeps] ; VOF_LIB selects an alternative build, VOF_SWEEP0M the kernel."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -19,6 +19,6 @@ for rep in range(3):
     s.bench_sweeps(movie, P, prm, NS)
     cnt, ms = s.profile_get("gs0", 0)
     by = s.profile_bytes("gs0", 0)
-    print(f"{os.environ.get('VOF_LIB', 'default')[-24:]:24s} pairs {P} sweeps {NS}: {cnt} launches, avg {1e3 * ms / cnt:8.1f} us, "
-          f"{by / ms / 1e6:7.0f} GB/s algorithmic (first launch is the from-zero sweep)")
+    print(f"{os.environ.get('VOF_LIB', 'default')[-24:]:24s} pairs {P} sweeps {NS}: {cnt} passes, {ms:8.2f} ms total = {1e3 * ms / NS:8.1f} us per sweep, "
+          f"{by / ms / 1e6:7.0f} GB/s on the bytes actually needed (the first sweep starts from zero)")
 s.close()

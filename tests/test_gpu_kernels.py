@@ -189,6 +189,36 @@ def test_fused_sweep_equals_colour_by_colour_order(native, kind, shape, npairs, 
                 np.testing.assert_array_equal(xg, xc)
 
 
+M_CASES = SWEEP_CASES + [("texture", (130, 258), 2, 1.0, 1e4, 8), ("random", (301, 250), 1, 0.7, 30.0, 9),
+                        ("texture", (6, 130), 1, 1.0, 1e4, 10), ("random", (77, 6), 2, 3.0, 2.0, 11)]
+
+
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", M_CASES)
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_level0_smoothing_passes_equal_colour_by_colour_order(native, kind, shape, npairs, alpha, beta, seed, quirks):
+    """The smoother as the cycle runs it on level 0 (k_sweep0m: merged colours, two sweeps per pass when the row length is
+    even; k_sweep0 otherwise) against nu x 4 launches of the per-colour kernel: bit for bit, forward and reverse order,
+    from zero and from a given x, one to three sweeps (three = one double pass + one single pass)."""
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, reference_quirks=quirks)
+    rng = np.random.default_rng(seed)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        if s.num_levels < 2:
+            pytest.skip("single-level grid")
+        b = s.debug_rhs()
+        x = rng.standard_normal(b.shape)
+        for nu in (1, 2, 3):
+            for reverse in (False, True):
+                for from_zero in (False, True):
+                    xg = s.debug_smooth(0, x, b, nu, reverse=reverse, from_zero=from_zero)
+                    xc = np.zeros_like(x) if from_zero else x.copy()
+                    for _ in range(nu):
+                        for colour in ((3, 2, 1, 0) if reverse else (0, 1, 2, 3)):
+                            xc = s.debug_gs(0, xc, b, colour)
+                    np.testing.assert_array_equal(xg, xc, err_msg=f"nu={nu} reverse={reverse} from_zero={from_zero}")
+
+
 @pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", SWEEP_CASES[1:4])
 @pytest.mark.parametrize("coarse_precision", [0, 1, 2])
 def test_fused_sweep_on_stored_levels(native, kind, shape, npairs, alpha, beta, seed, coarse_precision):
