@@ -57,19 +57,25 @@ def main():
         # Level-0-only kernels: the band height adapts to the number of active pairs, so one solve launches the same
         # symbol with several grid sizes -> per-launch mean over all of them (what bench.py's per-launch figure is).
         # Stored-level kernels share a symbol across levels: label the grid with the largest total traffic (level 1).
-        names = {"k_sweep<vof::SweepFine": ("gs0", 0, True), "k_sweep<vof::SweepStored": ("gs", 1, False),
-                 "k_stream_apply0<0": ("apply0", 0, True), "k_apply<": ("residual", 1, False)}
+        # bench.py's classes: gs0 = every level-0 smoother pass (k_sweep0m / k_sweep0 / k_sweep<SweepFine> instantiations),
+        # apply0 = the level-0 operator kernels.  Their per-launch figure is the mean over ALL launches of the class.
+        merged = {"gs0": ("k_sweep0m<", "k_sweep0<", "k_sweep<vof::SweepFine"), "apply0": ("k_stream_apply0<", "k_stream_resrestrict0<")}
+        for nm, pats in merged.items():
+            lst = [(sym, t) for sym, l2 in by_sym.items() if any(pt in sym for pt in pats) for t in l2]
+            if not lst:
+                continue
+            n = sum(t[1] for _, t in lst)
+            rd = sum(t[1] * t[2] for _, t in lst) / n
+            wr = sum(t[1] * t[3] for _, t in lst) / n
+            out[f"{nm}_L0_{size}x{size}x{frames}"] = {"hbm_bytes_per_launch": rd + wr, "fetch_x2_bytes": rd, "write_bytes": wr, "launches": n,
+                                                     "kernel": sorted({sym for sym, _ in lst}), "grid": sorted({t[0] for _, t in lst})}
+        # stored-level kernels share a symbol across levels: label the grid with the largest total traffic (level 1)
+        names = {"k_sweep<vof::SweepStored": ("gs", 1), "k_apply<": ("residual", 1)}
         for sym, lst in by_sym.items():
-            for pat, (nm, level, merge) in names.items():
+            for pat, (nm, level) in names.items():
                 if pat not in sym:
                     continue
-                if merge:
-                    n = sum(t[1] for t in lst)
-                    rd = sum(t[1] * t[2] for t in lst) / n
-                    wr = sum(t[1] * t[3] for t in lst) / n
-                    grid = sorted(t[0] for t in lst)
-                else:
-                    grid, n, rd, wr = max(lst, key=lambda t: t[1] * (t[2] + t[3]))
+                grid, n, rd, wr = max(lst, key=lambda t: t[1] * (t[2] + t[3]))
                 k = f"{nm}_L{level}_{size}x{size}x{frames}"
                 if k in out and out[k]["launches"] * out[k]["hbm_bytes_per_launch"] >= n * (rd + wr):
                     continue       # several template instantiations of one class: keep the busiest
