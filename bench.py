@@ -263,12 +263,15 @@ def main():
     with_bytes = [r for r in table if solver.profile_bytes(r[0], r[1]) > 0]
     dom = max(with_bytes or table, key=lambda r: r[3])
     alg_total = sum(solver.profile_bytes(r[0], r[1]) for r in table)
+    moved_total = sum(solver.profile_moved(r[0], r[1]) for r in table)
     counted_ms = sum(r[3] for r in with_bytes)
     if args.profile_table and rank == 0:
         for name, lvl, cnt, ms in sorted(table, key=lambda r: -r[3]):
             gb = solver.profile_bytes(name, lvl) / 1e9
+            mv = solver.profile_moved(name, lvl) / 1e9
             print(f"  {name:13s} L{lvl:<2d} launches {cnt:7d}  total {ms:10.3f} ms  avg {1e3 * ms / cnt:9.2f} us  "
-                  f"{100 * ms / total_ms:5.1f}%  {gb / (ms * 1e-3) if gb else 0:8.0f} GB/s", file=sys.stderr)
+                  f"{100 * ms / total_ms:5.1f}%  {gb / (ms * 1e-3) if gb else 0:8.0f} GB/s"
+                  + (f"  ({mv / (ms * 1e-3):.0f} GB/s moved)" if abs(mv - gb) > 1e-6 * gb else ""), file=sys.stderr)
         print(f"  all kernels: {total_ms:.1f} ms of GPU time per warm-up step set, {alg_total / 1e9:.1f} GB algorithmic "
               f"({alg_total / 1e9 / (total_ms * 1e-3):.0f} GB/s over all kernel time)", file=sys.stderr)
     dom_name, dom_level = dom[0], dom[1]
@@ -295,6 +298,7 @@ def main():
     units = solver.profile_units(dom_name, dom_level)      # frame pairs actually processed, summed over launches
     pix_per_launch = (units / cnt) * li * lj if cnt else 0.0
     alg_bytes = solver.profile_bytes(dom_name, dom_level)   # exact: summed by the library per launch
+    moved_bytes = solver.profile_moved(dom_name, dom_level)
     solver.profile_enable(False)
     bpp = algorithmic_bytes_per_pixel(dom_name, coarse_bytes)
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
@@ -335,10 +339,18 @@ def main():
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "launches": cnt, "pairs_per_launch": (units / cnt) if cnt else None, "avg_launch_us": 1e6 * avg_s if cnt else None,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
+                     # algorithmic bytes = 80 per pixel and SWEEP performed (56 from a zero guess, 86 with
+                     # the interpolated coarse-grid correction).  One pass of the level-0 smoother performs two sweeps
+                     # (temporal blocking in LDS), so it moves about half of that: "moved" is the minimal traffic of the pass,
+                     # the figure `traffic` (PMC) is to be compared with.
+                     "moved_bytes_per_launch": (moved_bytes / cnt) if cnt else None,
+                     "achieved_moved": (moved_bytes / cnt / avg_s / 1e9) if cnt else None,
                      "share_of_gpu_time": dom[3] / total_ms,
                      # the whole solve, not only the dominant kernel: algorithmic bytes of every byte-counted launch of the
                      # warm-up step(s) over the step time (HIP-event profile of the warm-up; set-up kernels count as time)
                      "whole_solve": {"algorithmic_bytes_per_step": alg_total / warm_steps,
+                                     "moved_bytes_per_step": moved_total / warm_steps,
+                                     "achieved_moved": moved_total / warm_steps / (dt / args.steps) / 1e9,
                                      "achieved": alg_total / warm_steps / (1e-3 * 1e3 * dt / args.steps) / 1e9,
                                      "frac": alg_total / warm_steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                      "kernel_time_share_with_byte_count": counted_ms / total_ms}},

@@ -99,6 +99,8 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *   VOF_FUSE_RESTRICT=0        level 0: separate residual and restriction kernels
  *   VOF_FUSE_PROLONG=0         level 0: separate prolongation kernel instead of interpolating inside the first post-sweep
  *   VOF_SWEEP0=0               level 0: the generic fused sweep kernel instead of the dedicated k_sweep0
+ *   VOF_FUSE_APPLY=0           the Krylov product after a cycle: separate operator kernel instead of the trailing stage of the
+ *                              cycle's last smoothing pass
  *   VOF_SWEEP0M=0|1            level 0, float64 vectors: 0 = the 4-wave kernel k_sweep0; 1 = k_sweep0m with one sweep per pass
  *                              (default: k_sweep0m, two sweeps per pass)
  *   VOF_COARSEST_MAX=3..9      coarsen until max(n_i, n_j) <= this (default 5); changes the hierarchy depth, hence iteration counts
@@ -196,6 +198,10 @@ int vof_profile_get_units(vof_ctx* ctx, int kernel_id, int level, int64_t* pair_
 /* Sum over the recorded launches of their algorithmic bytes (bytes per pixel of DESIGN.md section 3 x
  * level pixels x pairs processed); 0 for kernel classes that do not report it. */
 int vof_profile_get_bytes(vof_ctx* ctx, int kernel_id, int level, double* algorithmic_bytes);
+/* Same sum with the bytes a launch minimally has to MOVE.  Equal to the algorithmic bytes except for the level-0 smoother
+ * k_sweep0m, where one pass over the data performs two sweeps (algorithmic: 80 bytes per pixel and sweep performed; moved:
+ * 80 per pixel and pass). */
+int vof_profile_get_moved(vof_ctx* ctx, int kernel_id, int level, double* moved_bytes);
 const char* vof_kernel_name(int kernel_id);
 
 /* ---- debug / test entry points: single building blocks on device memory of the context -------
@@ -215,6 +221,9 @@ int vof_debug_prolong_add(vof_ctx* ctx, int level, double* fine_host, const doub
 int vof_debug_stencil(vof_ctx* ctx, int level, double* c_host); /* [pair][81][n_i][n_j], level >= 1 */
 int vof_debug_vcycle(vof_ctx* ctx, const double* r_host, double* e_host);
 int vof_debug_coarse_solve(vof_ctx* ctx, const double* r_host, double* e_host);
+/* y = M r (one cycle), v = A y, dots[2 k] = (v, r), dots[2 k + 1] = (v, v) of pair k - the Krylov step as the solver runs it;
+ * *fused = 1 if the product came out of the cycle's last smoothing pass (k_sweep0m's trailing stage) */
+int vof_debug_vcycle_apply(vof_ctx* ctx, const double* r_host, double* y_host, double* v_host, double* dots_host, int* fused);
 
 #ifdef __cplusplus
 }

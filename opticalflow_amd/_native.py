@@ -77,6 +77,7 @@ SIGNATURES = {
     "vof_profile_get": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "vof_profile_get_units": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "vof_profile_get_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "vof_profile_get_moved": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "vof_kernel_name": (C.c_char_p, [C.c_int]),
     "vof_debug_setup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams)]),
     "vof_debug_level_shape": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "vof_debug_stencil": (C.c_int, [_vp, C.c_int, _vp]),
     "vof_debug_vcycle": (C.c_int, [_vp, _vp, _vp]),
     "vof_debug_coarse_solve": (C.c_int, [_vp, _vp, _vp]),
+    "vof_debug_vcycle_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -318,6 +320,12 @@ class Solver:
         self._check(self.lib.vof_profile_get_bytes(self.h, kid, level, C.byref(u)), "profile_get_bytes")
         return u.value
 
+    def profile_moved(self, kernel: int | str, level: int = -1):
+        kid = K_NAMES.index(kernel) if isinstance(kernel, str) else int(kernel)
+        u = C.c_double()
+        self._check(self.lib.vof_profile_get_moved(self.h, kid, level, C.byref(u)), "profile_get_moved")
+        return u.value
+
     def profile_table(self):
         rows = []
         for kid, name in enumerate(K_NAMES):
@@ -392,6 +400,15 @@ class Solver:
         e = np.empty_like(r)
         self._check(self.lib.vof_debug_vcycle(self.h, _ptr(r), _ptr(e)), "debug_vcycle")
         return e
+
+    def debug_vcycle_apply(self, r):
+        """(y, v, dots, fused): y = M r, v = A y, dots[k] = ((v, r), (v, v)) of pair k."""
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(self._vec(0))
+        y, v = np.empty_like(r), np.empty_like(r)
+        dots = np.zeros((r.shape[0], 2))
+        fused = C.c_int(0)
+        self._check(self.lib.vof_debug_vcycle_apply(self.h, _ptr(r), _ptr(y), _ptr(v), _ptr(dots), C.byref(fused)), "debug_vcycle_apply")
+        return y, v, dots, bool(fused.value)
 
     def debug_coarse_solve(self, r):
         last = self.num_levels - 1

@@ -45,7 +45,8 @@ struct Level {
 struct ProfRec {
     hipEvent_t e0, e1;
     int kid, level, units;
-    double bytes;  // algorithmic bytes of this launch (units x bytes per pair)
+    double bytes;  // algorithmic bytes of this launch (units x bytes per pair; SURVEY 8(d): per sweep / operator application performed)
+    double moved;  // minimal bytes the launch has to move (differs when one pass performs two sweeps)
 };
 
 }  // namespace
@@ -112,6 +113,12 @@ struct vof_ctx {
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     bool sweep0 = true;         // level 0: dedicated k_sweep0 kernel (VOF_SWEEP0=0: the generic k_sweep<SweepFine, GeoA>)
+    // Krylov product fused into the last smoothing pass of a cycle (k_sweep0m's trailing stage): requested by the Krylov loop
+    // before the cycle, consumed by the final level-0 smoothing call if the fused path applies
+    bool trail_enabled = true;  // VOF_FUSE_APPLY=0: always the separate operator kernel
+    bool trail_set = false, trail_done = false;
+    S0Trail trail_req;
+    int trail_nblk = 0;         // per-pair partial sums the fused pass wrote
     bool sweep0m = true;        // level 0, float64 vectors, even n_j: k_sweep0m (VOF_SWEEP0M=0: k_sweep0)
     bool sweep0m_pairs = true;  // ... two sweeps per pass (VOF_SWEEP0M=1: one sweep per pass)
     bool tail_enabled = true;   // fused LDS-resident coarse-tail kernel (VOF_COARSE_TAIL=0: one launch per operation)
@@ -129,6 +136,7 @@ struct vof_ctx {
     long long prof_n[VOF_K_COUNT][16];
     long long prof_units[VOF_K_COUNT][16];
     double prof_bytes[VOF_K_COUNT][16];
+    double prof_moved[VOF_K_COUNT][16];
     int cur_units = 0;  // frame pairs the next launches process (active pairs of the batch)
 };
 
@@ -140,7 +148,7 @@ struct Prof {
     vof_ctx* c;
     bool on;
     ProfRec rec;
-    Prof(vof_ctx* c_, int kid, int level, double bytes_per_pair = 0.0) : c(c_), on(false) {
+    Prof(vof_ctx* c_, int kid, int level, double bytes_per_pair = 0.0, double moved_per_pair = -1.0) : c(c_), on(false) {
         if (!c->prof) return;
         if (c->prof_kid >= 0 && kid != c->prof_kid) return;
         if (c->prof_level >= 0 && level != c->prof_level) return;
@@ -154,6 +162,7 @@ struct Prof {
         rec.kid = kid; rec.level = level < 0 ? 0 : (level > 15 ? 15 : level);
         rec.units = c->cur_units;
         rec.bytes = bytes_per_pair * c->cur_units;
+        rec.moved = (moved_per_pair < 0.0 ? bytes_per_pair : moved_per_pair) * c->cur_units;
         on = true;
         hipEventRecord(rec.e0, c->stream);
     }
@@ -174,6 +183,7 @@ void prof_collect(vof_ctx* c) {
             c->prof_n[r.kid][r.level] += 1;
             c->prof_units[r.kid][r.level] += r.units;
             c->prof_bytes[r.kid][r.level] += r.bytes;
+            c->prof_moved[r.kid][r.level] += r.moved;
         }
         c->free_events.push_back(r.e0);
         c->free_events.push_back(r.e1);
@@ -380,7 +390,7 @@ inline bool sweep0m_usable(const vof_ctx* c) {
 // nsweeps = 2 (level 0, k_sweep0m only): two consecutive sweeps in one pass.
 template <typename VT>
 void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
-                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1) {
+                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1, bool with_trail = false) {
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
     int rows = lv.ni + po;
@@ -388,7 +398,8 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         if (l == 0 && lv.C == nullptr && sweep0m_usable(c)) {
             // k_sweep0m: merged colours, 16-byte accesses, `nsweeps` (1 or 2) sweeps per pass; strips are not shifted by po
             const int NSW = nsweeps >= 2 ? 2 : 1;
-            const int out = S0_W - 8 * NSW;
+            const bool trail = with_trail && x_in != nullptr;
+            const int out = S0_W - 8 * NSW - (trail ? 4 : 0);
             const int nx = (lv.nj + out - 1) / out;
             const int TI = pick_band_height(rows, nx, c->cur_units);
             const int ny = (rows + TI - 1) / TI;
@@ -396,15 +407,29 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             int nci = 0, ncj = 0;
             double ebytes = 0.0;
             if (ecoarse) { nci = c->L[1].ni; ncj = c->L[1].nj; ebytes = 24.0 * c->L[1].npts; }
-            // algorithmic bytes of the pass: I + b(3) + x(3) in, x(3) out (+ coarse e), whatever the number of fused sweeps
-            Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * 8.0) * lv.npts + ebytes);
+            // bytes the pass moves: I + b(3) + x(3) in, x(3) out (+ coarse e), whatever the number of fused sweeps; algorithmic
+            // bytes (80 per sweep performed): the second sweep of a double pass counts as a full sweep
+            double moved = (8.0 + (x_in ? 9.0 : 6.0) * 8.0) * lv.npts + ebytes;
+            double algo = moved + (NSW - 1) * 80.0 * lv.npts;
+            S0Trail tr{nullptr, nullptr, 0, nullptr};
+            if (trail) {   // + the operator product v = A x_out with its dot products: algorithmic 56 (+24 for the dot partner)
+                tr = c->trail_req;
+                const double dv = tr.dotvec ? 24.0 : 0.0;
+                algo += (56.0 + dv) * lv.npts;
+                moved += (24.0 + dv) * lv.npts;     // only v out and the dot partner in: x_out and the image are in LDS
+                c->trail_nblk = nx * ny;
+                c->trail_done = true;
+            }
+            Prof p(c, VOF_K_GS0, 0, algo, moved);
             Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, c->prm.reference_quirks, c->pp};
-            const size_t lds = (size_t)(6 * NSW + 2) * s0_row_bytes(8) + (ecoarse ? (size_t)9 * (S0_W / 2 + 2) * 8 : 0);
+            const size_t lds = (size_t)(6 * NSW + 2 + (trail ? 4 : 0)) * s0_row_bytes(8) + (ecoarse ? (size_t)9 * (S0_W / 2 + 2) * 8 : 0);
 #define VOF_LAUNCH_S0M(NS_)                                                                                                        \
             do {                                                                                                                    \
-                if (ecoarse) k_sweep0m<NS_, true, false><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
-                else if (!x_in) k_sweep0m<NS_, false, true><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
-                else k_sweep0m<NS_, false, false><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
+                if (trail && ecoarse) k_sweep0m<NS_, true, false, 1><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (trail) k_sweep0m<NS_, false, false, 1><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (ecoarse) k_sweep0m<NS_, true, false, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (!x_in) k_sweep0m<NS_, false, true, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else k_sweep0m<NS_, false, false, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
             if (NSW == 2) VOF_LAUNCH_S0M(2); else VOF_LAUNCH_S0M(1);
 #undef VOF_LAUNCH_S0M
@@ -450,7 +475,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
 // nu sweeps (from a zero guess if from_zero, else from x); the result is guaranteed to end in `x`.
 template <typename VT>
 VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
-                   const int* active, const VT* ecoarse = nullptr, bool allow_swap = false) {
+                   const int* active, const VT* ecoarse = nullptr, bool allow_swap = false, bool final_smooth = false) {
     // Returns the buffer that holds the result: `x`, or `tmp` when allow_swap is set and the last out-of-place sweep
     // ended there (saves a device-to-device copy on the coarse levels).
     // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
@@ -482,7 +507,10 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
     int left = nu;
     for (int s = 0; s < npass; ++s) {
         const int ns = two ? std::min(2, left) : 1;
-        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns);
+        // the cycle's very last pass also delivers the Krylov product of its result, if one was requested
+        const bool trail = final_smooth && s == npass - 1 && c->trail_set && c->trail_enabled && l == 0 &&
+                           std::is_same<VT, double>::value && sweep0m_usable(c) && src != nullptr;
+        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns, trail);
         left -= ns;
         src = dst;
         dst = (dst == x) ? tmp : x;
@@ -572,7 +600,7 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
             ec = vcycle_t<VT>(c, l + 1, ec, other, (const VT*)nx.b, np, active, false);
         }
     }
-    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/true);
+    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/true, /*final_smooth=*/l == 0);
 }
 
 // One cycle M b -> *xslot (c->ky or c->kz).  The out-of-place sweeps may leave the result in the level-0 ping-pong partner
@@ -841,8 +869,12 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         const double vsz = c->vfloat ? 4.0 : 8.0;
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));   // p = r + beta (p - omega v)
           VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
-        vcycle(c, &c->ky, vrhs_p, np, act);                             // y = M p
-        int nb1 = krylov_apply(c, c->ky, c->kv, np, act, c->krh, 0);   // v = A y, fused (r^, v)
+        // y = M p and v = A y with (r^, v): the product comes out of the cycle's last smoothing pass when that path applies
+        c->trail_req = S0Trail{c->kv, c->krh, 0, c->partials};
+        c->trail_set = true; c->trail_done = false;
+        vcycle(c, &c->ky, vrhs_p, np, act);
+        c->trail_set = false;
+        int nb1 = c->trail_done ? c->trail_nblk : krylov_apply(c, c->ky, c->kv, np, act, c->krh, 0);
         if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, nb1, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 3 + (c->vfloat ? 4.0 * len : 0.0));   // s = r - alpha v, (s, s)
@@ -851,8 +883,12 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         { Prof p(c, VOF_K_VECTOR, 0);                                  // pairs done at the half step: x += alpha y
           VDISPATCH(c, (k_fix_half<VT><<<dim3(64, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, len, c->sc)));
           k_clear_half<<<(np + 255) / 256, 256, 0, s>>>(c->sc, np); }
-        vcycle(c, &c->kz, vrhs_s, np, act);                             // z = M s
-        int nb2 = krylov_apply(c, c->kz, c->kt, np, act, c->kr, 1);    // t = A z, fused (t, s) and (t, t)
+        // z = M s and t = A z with (t, s) and (t, t)
+        c->trail_req = S0Trail{c->kt, c->kr, 1, c->partials};
+        c->trail_set = true; c->trail_done = false;
+        vcycle(c, &c->kz, vrhs_s, np, act);
+        c->trail_set = false;
+        int nb2 = c->trail_done ? c->trail_nblk : krylov_apply(c, c->kz, c->kt, np, act, c->kr, 1);
         if (!nb2) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); nb2 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, nb2, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 6 + 2.0 * vsz * len);   // x += alpha y + omega z; r = s - omega t; (r,r), (r^,r)
@@ -1060,6 +1096,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_units, 0, sizeof c->prof_units);
     memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+    memset(c->prof_moved, 0, sizeof c->prof_moved);
     vof_default_params(&c->prm, sizeof c->prm);
     if (const char* e = getenv("VOF_SWEEP_GEO")) {   // experiment switch: "AA", "AB" (default), "BA", "BB" = fine,stored
         c->geo_b_fine = e[0] == 'B';
@@ -1070,6 +1107,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
+    if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0M")) { c->sweep0m = e[0] != '0'; c->sweep0m_pairs = e[0] != '0' && e[0] != '1'; }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
@@ -1135,9 +1173,17 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     }
     if (int rc = dev_alloc(c, &c->W, (size_t)B * c->nd * 2 * c->nd)) return rc;
     if (int rc = dev_alloc(c, &c->invT, (size_t)B * c->nd * c->nd)) return rc;
+    {   // the level-0 smoother passes with the trailing stage need more than the default 64 KB of dynamic LDS
+        const int lds = 18 * s0_row_bytes(8) + 9 * (S0_W / 2 + 2) * 8;
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep0m<2, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep0m<2, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep0m<1, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_sweep0m<1, false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     c->nblk = (int)std::min<size_t>(256, std::max<size_t>(1, (len0 + 4 * RBLK - 1) / (4 * RBLK)));
     {
         int nblk_apply = ((l0.nj + AP_OUT - 1) / AP_OUT) * ((l0.ni + 31) / 32 + 1);   // smallest band height: 32 rows
+        nblk_apply = std::max(nblk_apply, ((l0.nj + 99) / 100) * ((l0.ni + 1 + 31) / 32 + 1));   // k_sweep0m's trailing stage (strips >= 108 columns)
         if (int rc = dev_alloc(c, &c->partials, (size_t)B * 3 * std::max(c->nblk, nblk_apply))) return rc;
     }
     if (int rc = dev_alloc(c, &c->sc, (size_t)B)) return rc;
@@ -1699,6 +1745,17 @@ int vof_profile_get_bytes(vof_ctx* c, int kid, int level, double* algorithmic_by
     return 0;
 }
 
+int vof_profile_get_moved(vof_ctx* c, int kid, int level, double* moved_bytes) {
+    if (!c) return -1;
+    if (kid < 0 || kid >= VOF_K_COUNT || level > 15) { c->err = "bad kernel id / level"; return -1; }
+    prof_collect(c);
+    double u = 0;
+    for (int l = 0; l < 16; ++l)
+        if (level < 0 || l == level) u += c->prof_moved[kid][l];
+    if (moved_bytes) *moved_bytes = u;
+    return 0;
+}
+
 int vof_profile_reset(vof_ctx* c) {
     if (!c) return -1;
     prof_collect(c);
@@ -1706,6 +1763,7 @@ int vof_profile_reset(vof_ctx* c) {
     memset(c->prof_n, 0, sizeof c->prof_n);
     memset(c->prof_units, 0, sizeof c->prof_units);
     memset(c->prof_bytes, 0, sizeof c->prof_bytes);
+    memset(c->prof_moved, 0, sizeof c->prof_moved);
     c->prof_dropped = 0;
     return 0;
 }
@@ -1914,6 +1972,35 @@ int vof_debug_vcycle(vof_ctx* c, const double* r_host, double* e_host) {
     if (int rc = dbg_up(c, c->kp, r_host, n)) return rc;
     vcycle(c, &c->ky, c->kp, c->npairs, nullptr);
     return dbg_down(c, e_host, c->ky, n);
+}
+
+// One multigrid cycle y = M r followed by the Krylov product v = A y with the dot products (v, r) and (v, v) per pair, as the
+// BiCGStab loop runs them (fused into the cycle's last smoothing pass when that path applies; `fused` reports it).
+int vof_debug_vcycle_apply(vof_ctx* c, const double* r_host, double* y_host, double* v_host, double* dots_host, int* fused) {
+    DBG_LEVEL(0)
+    size_t n = nbytes / sizeof(double);
+    if (int rc = dbg_up(c, c->kp, r_host, n)) return rc;
+    const int np = c->npairs;
+    c->cur_units = np;
+    HIPCHK(hipMemcpyAsync(c->krh, r_host, nbytes, hipMemcpyHostToDevice, c->stream));   // dot partner (float64)
+    c->trail_req = S0Trail{c->kv, c->krh, 1, c->partials};
+    c->trail_set = true; c->trail_done = false;
+    vcycle(c, &c->ky, c->kp, np, nullptr);
+    c->trail_set = false;
+    int nb = c->trail_done ? c->trail_nblk : krylov_apply(c, c->ky, c->kv, np, nullptr, c->krh, 1);
+    if (fused) *fused = c->trail_done ? 1 : 0;
+    if (!nb) { c->err = "the operator kernel did not fuse the dot products"; return -1; }
+    std::vector<double> part((size_t)np * 3 * nb);
+    HIPCHK(hipMemcpyAsync(part.data(), c->partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = dbg_down(c, y_host, c->ky, n)) return rc;
+    HIPCHK(hipMemcpy(v_host, c->kv, nbytes, hipMemcpyDeviceToHost));
+    for (int k = 0; k < np; ++k)
+        for (int sl = 0; sl < 2; ++sl) {
+            double a = 0;
+            for (int i = 0; i < nb; ++i) a += part[((size_t)k * 3 + sl) * nb + i];
+            dots_host[2 * k + sl] = a;
+        }
+    return 0;
 }
 
 int vof_debug_coarse_solve(vof_ctx* c, const double* r_host, double* e_host) {

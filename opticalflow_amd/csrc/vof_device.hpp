@@ -2182,19 +2182,73 @@ __global__ __launch_bounds__(S0_THREADS) void k_sweep0(Fine0 pol, int ni, int nj
 // Column validity after stage c' (0..3 in processing order) of sweep k: local columns [2 - po + c' + 4k, 126 - po - c' - 4k];
 // owned columns [4 NS, 128 - 4 NS).  Row ranges: E_k [-2 m, TI + 2 m], O_k [-2 m + 1, TI + 2 m - 1] with m = NS - 1 - k.
 // ==========================================================================================
-template <int NS> struct S0M {
-    static constexpr int THREADS = 128 * NS, NW = 2 * NS, R = 6 * NS + 2, HALO = 4 * NS, OUT = S0_W - 8 * NS;
+// TRAIL = 1 adds a trailing stage: after its two colours every wave applies the level-0 operator to a half-row of the rows
+// that have just become final, v = A x_out (+ the BiCGStab dot products (v, dotvec) / (v, v)), i.e. the Krylov product that
+// follows the cycle comes out of the same pass instead of re-reading y and the image (32 of its 80 bytes per pixel, and a
+// launch).  It needs the rows around a final row to be final as well: one more halo column pair per side
+// (OUT = 128 - 8 NS - 4), two more halo rows per band side (EXT = 1) and a ring four rows deeper (rows are written out two
+// steps later).  (Two extra waves for the stage were tried first: 6 waves at ~200 registers leave room for one workgroup
+// per CU only, and the pass took as long as the separate kernel it replaced.)
+template <int NS, int TRAIL = 0> struct S0M {
+    static constexpr int EXT = TRAIL ? 1 : 0;
+    static constexpr int NW = 2 * NS;                     // waves: sweep k = wave / 2, even-row / odd-row wave = wave % 2
+    static constexpr int THREADS = 64 * NW;
+    // rows e - WOFF, e - WOFF + 1 are written out at step e and their slots refilled at its end, so nothing may read them in
+    // that step: the trailing stage (rows e - 6 NS, + 1, reading e - 6 NS - 1 .. e - 6 NS + 2) pushes the write-out 4 rows back
+    static constexpr int WOFF = 6 * NS + 4 * EXT;
+    static constexpr int R = WOFF + 2;                    // ring rows (8 / 14 without, 12 / 18 with the trailing stage)
+    static constexpr int HALO = 4 * NS + 2 * EXT, OUT = S0_W - 2 * HALO;
     static constexpr int RSB = 3 * S0_W * 8 + S0_IW * 8;   // ring row: 3 x 128 doubles of x, 132 doubles of image
     static constexpr int CRW = S0_W / 2 + 2;               // coarse ring width
 };
 
-template <int NS, bool EC, bool FROM_ZERO>
-__global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj, int TI, int po, int nx, int ny, int nz,
-                                                       const double* __restrict__ x_in, double* __restrict__ x_out,
-                                                       const double* __restrict__ b, const int* __restrict__ active,
-                                                       const double* __restrict__ ecoarse, int nci, int ncj) {
-    typedef S0M<NS> G;
+// Full operator product (A x)(p, q) of level 0 at one point from the 3x3 neighbourhoods of the image and of x (ghosts folded
+// by the caller, corner factors applied here), in the style of gs0_point.
+template <bool CORNERS>
+__device__ __forceinline__ void apply0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
+                                             double alpha, double beta, int quirks, double& y0, double& y1, double& y2) {
+    const double P = im[4];
+    const double Dx = (im[7] - im[1]) * 0.5;
+    const double Dy = quirks ? Dx : (im[5] - im[3]) * 0.5;
+    const double Dxx = fma(-2.0, P, im[7] + im[1]);
+    const double Dyy = fma(-2.0, P, im[5] + im[3]);
+    const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;
+    const double PP = P * P, PDx = P * Dx, PDy = P * Dy, hP = 0.5 * P;
+    const double A1 = PP + alpha, qPP = 0.25 * PP, hPDx = 0.5 * PDx, hPDy = 0.5 * PDy;
+    const double du71 = n.u[7] - n.u[1], du53 = n.u[5] - n.u[3], dw71 = n.w[7] - n.w[1], dw53 = n.w[5] - n.w[3];
+    double W4, U4;
+    if (CORNERS) {
+        W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
+        U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+    } else {
+        W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
+        U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+    }
+    const double m4a = -4.0 * alpha;
+    const double axx = fma(P, fma(-2.0, P, Dxx), m4a), ayy = fma(P, fma(-2.0, P, Dyy), m4a), c = P * Dxy;
+    y0 = fma(hPDx, dw53, fma(alpha, n.u[3] + n.u[5], A1 * (n.u[1] + n.u[7]))) +
+         fma(hP, n.g[1] - n.g[7], fma(qPP, W4, fma(hPDy, dw71, PDx * du71))) + fma(axx, n.u[4], c * n.w[4]);
+    y1 = fma(hPDy, du71, fma(alpha, n.w[1] + n.w[7], A1 * (n.w[3] + n.w[5]))) +
+         fma(hP, n.g[3] - n.g[5], fma(qPP, U4, fma(hPDx, du53, PDy * dw53))) + fma(ayy, n.w[4], c * n.u[4]);
+    y2 = fma(hP, du71 + dw53, beta * ((n.g[1] + n.g[7]) + (n.g[3] + n.g[5]))) +
+         fma(Dy, n.w[4], fma(Dx, n.u[4], (-1.0 - 4.0 * beta) * n.g[4]));
+}
+
+struct S0Trail {           // trailing operator stage (TRAIL = 1): v = A x_out, partial sums of (v, dotvec) and / or (v, v)
+    double* v;            // [pair][3][npts]
+    const double* dotvec; // or nullptr
+    int want_vv;          // slot 0 = (v, dotvec) or, without dotvec, (v, v); slot 1 = (v, v) when both are asked for
+    double* partials;     // [pair][3][nblk], nblk = nx * ny blocks per pair
+};
+
+template <int NS, bool EC, bool FROM_ZERO, int TRAIL = 0>
+__global__ __launch_bounds__(128 * NS) void k_sweep0m(
+    Fine0 pol, int ni, int nj, int TI, int po, int nx, int ny, int nz, const double* __restrict__ x_in,
+    double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
+    const double* __restrict__ ecoarse, int nci, int ncj, S0Trail tr) {
+    typedef S0M<NS, TRAIL> G;
     constexpr int W = S0_W, IW = S0_IW, NW = G::NW, R = G::R, RSB = G::RSB, RINGB = R * RSB, CRW = G::CRW;
+    constexpr int EXT = G::EXT, WOFF = G::WOFF;
     constexpr int FB = W * 8, XB = 3 * FB, HB = (W / 2) * 8, IHB = (IW / 2) * 8;   // field stride, image part, parity halves
     extern __shared__ double sw_lds[];
     char* ring = reinterpret_cast<char*>(sw_lds);
@@ -2225,8 +2279,11 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
     // ---- this wave's stage: sweep k, even-row (E) or odd-row (O) wave
     const int sk = wave >> 1, odd = wave & 1;
     const int soff = -6 * sk - 3 * odd;                       // row of the stage relative to e
-    const int m = NS - 1 - sk;
+    const int m = NS - 1 - sk + EXT;
     const int rr_lo = -2 * m + odd, rr_hi = TI + 2 * m - odd;
+    // ---- trailing operator stage (TRAIL): the four half-rows (row e - 6 NS + r, ring columns 64 h .. 64 h + 63), r, h = 0, 1,
+    // are dealt to the waves: job j = 2 r + h goes to wave j % NW; a lane handles ONE column there
+    constexpr int NJOB = TRAIL ? 4 / NW : 0;                  // jobs per wave (NW = 2: 2, NW = 4: 1)
     // lane <-> column pair (2 lane, 2 lane + 1); pair validity is all-or-nothing (qs and nj are even)
     const int qpair = qs + 2 * lane;
     const bool pair_ok = qpair >= 0 && qpair + 1 < nj;
@@ -2243,7 +2300,7 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
     auto cr_slot = [](int k) { return ((k % 3) + 3) % 3; };
     if (EC) {   // prologue: the two coarse rows the first load-in step needs
         if (wave == 0) {
-            const int k0 = (p0 - 2 * NS) >> 1;   // the first step loads fine rows p0 - 2 NS, p0 - 2 NS + 1: coarse rows k0, k0 + 1
+            const int k0 = (p0 - 2 * (NS + EXT)) >> 1;   // the first step loads fine rows p0 - 2 (NS + EXT), + 1: coarse rows k0, k0 + 1
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 const int k = k0 + d;
@@ -2261,32 +2318,43 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
         __syncthreads();
     }
 
-    // ---- running state (advanced by two rows per step); first step: e = -2 NS - 2 (loads rows -2 NS, -2 NS + 1)
-    const int s_first = -NS - 1, s_last = TI / 2 + 3 * NS - 1;
+    // ---- running state (advanced by two rows per step); first step: e = -2 (NS + EXT) - 2 (loads rows -2 (NS + EXT), + 1);
+    // last step: writes out row TI - 1 = e - WOFF + 1
+    const int s_first = -(NS + EXT) - 1, s_last = (TI + WOFF - 2) / 2;
     const int e0 = 2 * s_first;
     auto wrapB = [](int t) { return t >= RINGB ? t - RINGB : t; };
     auto slot_of = [](int row) { return ((row % R) + R) % R; };
     int ringL = slot_of(e0 + 2) * RSB;                         // ring row of relative row e + 2 (row e + 3 follows, wrapped)
     int rowC = slot_of(e0 + soff) * RSB;                       // ring row of the stage's row e + soff
     long long gL = (long long)(p0 + e0 + 2) * nj;              // x row e + 2 (elements); e + 3 is one row further
-    long long gW = (long long)(p0 + e0 - 6 * NS) * nj;         // x row e - 6 NS being written out
+    long long gW = (long long)(p0 + e0 - WOFF) * nj;           // x row e - WOFF being written out
     long long gI = (long long)(p0 + e0 + 3) * Nj;              // full-image row of relative row e + 2
     long long gB = (long long)(p0 + e0 + 2 + soff) * nj;       // b row of the stage's NEXT row
+    long long gT = (long long)(p0 + e0 - 6 * NS) * nj;         // trailing stage: row e - 6 NS
+    int rowT = slot_of(e0 - 6 * NS) * RSB;
     // steps in which every row any wave touches exists and is an interior row (no predicates, no ghost rows, no corners)
-    int e_lo = 6 * NS, e_hi = TI + 2 * NS - 4;
-    e_lo = max(e_lo, 6 * NS - p0);  e_hi = min(e_hi, ni - 4 - p0);                         // stores / loads inside the image
+    int e_lo = WOFF, e_hi = TI + 2 * (NS + EXT) - 4;
+    e_lo = max(e_lo, WOFF - p0);  e_hi = min(e_hi, ni - 4 - p0);                           // stores / loads inside the image
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) {
-        const int k2 = w2 >> 1, o2 = w2 & 1, of2 = -6 * k2 - 3 * o2, m2 = NS - 1 - k2;
+        const int k2 = w2 >> 1, o2 = w2 & 1, of2 = -6 * k2 - 3 * o2, m2 = NS - 1 - k2 + EXT;
         const int lo2 = -2 * m2 + o2, hi2 = TI + 2 * m2 - o2;
         e_lo = max(e_lo, max(lo2 - of2, 1 - p0 - of2));
         e_hi = min(e_hi, min(hi2 - of2 - 2, ni - 3 - p0 - of2));
     }
+    if (TRAIL) {   // trailing rows e - 6 NS, + 1 in [0, TI), interior, and the dot partner's row two further exists
+        e_lo = max(e_lo, max(6 * NS, 6 * NS + 1 - p0));
+        e_hi = min(e_hi, min(TI + 6 * NS - 4, ni - 5 - p0 + 6 * NS));
+    }
     double2 bn0 = {0, 0}, bn1 = {0, 0}, bn2 = {0, 0};   // b of the stage's row for the NEXT step (prefetched)
+    double ts0 = 0.0, ts1 = 0.0;                          // trailing stage: partial dot products of this lane
+    double tn[NJOB > 0 ? NJOB : 1][3];                    // ... and the dot partner's values for the NEXT step (prefetched)
+#pragma unroll
+    for (int j = 0; j < (NJOB > 0 ? NJOB : 1); ++j) tn[j][0] = tn[j][1] = tn[j][2] = 0.0;
 
     auto step = [&](auto edge_tag, const int e) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        const bool do_load = EDGE ? (e + 3 <= TI + 2 * NS - 1) : true;
+        const bool do_load = EDGE ? (e + 3 <= TI + 2 * (NS + EXT) - 1) : true;
         // ---- (1) write-out and (2) loads: this wave's items
         double2 lx[3] = {{0, 0}, {0, 0}, {0, 0}};   // at most 3 x items per wave (NW = 2); NW = 4: 2
         double2 li = {0, 0}, lix = {0, 0};
@@ -2297,8 +2365,8 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
             if (fr < 6) {
                 const int row = fr >= 3 ? 1 : 0, f = fr - 3 * row;
                 const int rofs = wrapB(ringL + row * RSB) + f * FB;
-                {   // write-out of relative row e - 6 NS + row
-                    const int rrW = e - 6 * NS + row;
+                {   // write-out of relative row e - WOFF + row
+                    const int rrW = e - WOFF + row;
                     const bool rowok = EDGE ? (rrW >= 0 && rrW < TI && p0 + rrW >= 0 && p0 + rrW < ni) : true;
                     if (rowok && st_ok) {
                         double2 v;
@@ -2352,16 +2420,16 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
         {
             const int rr = e + soff, p = p0 + rr;
             const bool rowok = EDGE ? (rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni) : true;
+            const int rowU = rowC >= RSB ? rowC - RSB : rowC + RINGB - RSB;
+            const int rowD = wrapB(rowC + RSB);
+            const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
+            const char* ru = ring + (oU ? rowD : rowU);   // ghost row -1 mirrors row 1, ghost row n mirrors row n - 2
+            const char* rc = ring + rowC;
+            const char* rd = ring + (oD ? rowU : rowD);
+            const char* iu = ring + rowU + XB;            // the image has real border rows: no folding
+            const char* ic = ring + rowC + XB;
+            const char* id = ring + rowD + XB;
             if (rowok) {
-                const int rowU = rowC >= RSB ? rowC - RSB : rowC + RINGB - RSB;
-                const int rowD = wrapB(rowC + RSB);
-                const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
-                const char* ru = ring + (oU ? rowD : rowU);   // ghost row -1 mirrors row 1, ghost row n mirrors row n - 2
-                const char* rc = ring + rowC;
-                const char* rd = ring + (oD ? rowU : rowD);
-                const char* iu = ring + rowU + XB;            // the image has real border rows: no folding
-                const char* ic = ring + rowC + XB;
-                const char* id = ring + rowD + XB;
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph) {
                     const int par = ph ^ po;                  // column parity of this phase (po is block-uniform)
@@ -2409,6 +2477,71 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
                     // fence only keeps the compiler from moving the reads above the writes)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        // ---- (4b) trailing stage: v = A x_out on the half-rows of this wave (rows e - 6 NS, + 1: final, and so are the rows
+        // around them), one column per lane, + the dot products
+        if (TRAIL) {
+#pragma unroll
+            for (int jb = 0; jb < NJOB; ++jb) {
+                const int job = wave + jb * NW, tr_r = job >> 1, th = job & 1;
+                const int rr = e - 6 * NS + tr_r, p = p0 + rr;
+                const int lc = 64 * th + lane, q = qs + lc;
+                const bool col_on = lc >= G::HALO && lc < W - G::HALO && q >= 0 && q < nj;
+                const size_t qv = col_on ? (size_t)q : 0;
+                const double t0 = tn[jb][0], t1 = tn[jb][1], t2 = tn[jb][2];
+                {   // the dot partner of the NEXT step's row
+                    const bool nrow = EDGE ? (rr + 2 >= 0 && rr + 2 < TI && p + 2 >= 0 && p + 2 < ni) : true;
+                    if (tr.dotvec && nrow && col_on) {
+                        const double* drow = tr.dotvec + off + (gT + (long long)(tr_r + 2) * nj) + qv;
+                        tn[jb][0] = drow[0]; tn[jb][1] = drow[npts]; tn[jb][2] = drow[2 * npts];
+                    }
+                }
+                const bool rowok = EDGE ? (rr >= 0 && rr < TI && p >= 0 && p < ni) : true;
+                if (rowok && col_on) {
+                    const int rC = wrapB(rowT + tr_r * RSB);
+                    const int rU = rC >= RSB ? rC - RSB : rC + RINGB - RSB, rD = wrapB(rC + RSB);
+                    const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
+                    const char* ru = ring + (oU ? rD : rU);
+                    const char* rc = ring + rC;
+                    const char* rd = ring + (oD ? rU : rD);
+                    const char* iu = ring + rU + XB;
+                    const char* ic = ring + rC + XB;
+                    const char* id = ring + rD + XB;
+                    const int par = lc & 1, jx = lc >> 1;
+                    const int oCn = par ? HB + jx * 8 : jx * 8;
+                    int oLn = par ? jx * 8 : HB + (jx - 1) * 8, oRn = par ? (jx + 1) * 8 : HB + jx * 8;
+                    const bool gl = q - 1 < 0, gr = q + 1 >= nj;
+                    { const int tl = oLn; if (gl) oLn = oRn; if (gr) oRn = tl; }
+                    const int i0 = par ? IHB + jx * 8 : jx * 8;
+                    const int i1 = par ? (jx + 1) * 8 : IHB + jx * 8;
+                    const int i2 = par ? IHB + (jx + 1) * 8 : (jx + 1) * 8;
+                    auto X = [](const char* r, int o) { return *reinterpret_cast<const double*>(r + o); };
+                    const double imv[9] = {X(iu, i0), X(iu, i1), X(iu, i2), X(ic, i0), X(ic, i1), X(ic, i2), X(id, i0), X(id, i1), X(id, i2)};
+                    Nbr n;
+                    n.u[0] = X(ru, oLn); n.w[0] = X(ru, FB + oLn);
+                    n.u[1] = X(ru, oCn); n.w[1] = X(ru, FB + oCn); n.g[1] = X(ru, 2 * FB + oCn);
+                    n.u[2] = X(ru, oRn); n.w[2] = X(ru, FB + oRn);
+                    n.u[3] = X(rc, oLn); n.w[3] = X(rc, FB + oLn); n.g[3] = X(rc, 2 * FB + oLn);
+                    n.u[4] = X(rc, oCn); n.w[4] = X(rc, FB + oCn); n.g[4] = X(rc, 2 * FB + oCn);
+                    n.u[5] = X(rc, oRn); n.w[5] = X(rc, FB + oRn); n.g[5] = X(rc, 2 * FB + oRn);
+                    n.u[6] = X(rd, oLn); n.w[6] = X(rd, FB + oLn);
+                    n.u[7] = X(rd, oCn); n.w[7] = X(rd, FB + oCn); n.g[7] = X(rd, 2 * FB + oCn);
+                    n.u[8] = X(rd, oRn); n.w[8] = X(rd, FB + oRn);
+                    double y0, y1, y2;
+                    if (EDGE) {
+                        const double sUL = (oU && gl) ? 2.0 : 1.0, sUR = (oU && gr) ? 2.0 : 1.0;
+                        const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
+                        apply0_point<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, quirks, y0, y1, y2);
+                    } else {
+                        apply0_point<false>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, quirks, y0, y1, y2);
+                    }
+                    double* vrow = tr.v + off + (gT + (long long)tr_r * nj) + qv;
+                    vrow[0] = y0; vrow[npts] = y1; vrow[2 * npts] = y2;
+                    const double vv = y0 * y0 + y1 * y1 + y2 * y2;
+                    if (tr.dotvec) { ts0 += y0 * t0 + y1 * t1 + y2 * t2; ts1 += vv; }
+                    else ts0 += vv;
                 }
             }
         }
@@ -2476,7 +2609,23 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(Fine0 pol, int ni, int nj,
         ringL = wrapB(ringL + 2 * RSB);
         rowC = wrapB(rowC + 2 * RSB);
         gL += 2 * (long long)nj; gW += 2 * (long long)nj; gB += 2 * (long long)nj; gI += 2 * (long long)Nj;
+        if (TRAIL) { gT += 2 * (long long)nj; rowT = wrapB(rowT + 2 * RSB); }
         __syncthreads();
+    }
+    if (TRAIL) {   // per-block partial sums of the dot products (the ring is dead: its first bytes serve as scratch)
+        double* red = reinterpret_cast<double*>(ring);
+        const double a0 = wave_sum(ts0), a1 = wave_sum(ts1);
+        if (lane == 0) { red[2 * wave] = a0; red[2 * wave + 1] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0 && tr.partials) {
+            const int nblk = nx * ny, blk = by * nx + bx;
+            double* pp = tr.partials + ((size_t)pair * 3) * nblk + blk;
+            double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) { q0 += red[2 * w2]; q1 += red[2 * w2 + 1]; }
+            pp[0] = q0;
+            if (tr.dotvec && tr.want_vv) pp[nblk] = q1;
+        }
     }
 }
 

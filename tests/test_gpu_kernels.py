@@ -329,3 +329,27 @@ def test_w_cycle_matches_prototype(native):
         r = s.debug_rhs()
         e = s.debug_vcycle(r)
         assert relerr(e[0], cyc(r[0], 0)) < 1e-9
+
+
+@pytest.mark.parametrize("shape,npairs,sweeps", [((130, 258), 2, None), ((301, 250), 1, (2, 1, 1, 1)), ((66, 66), 2, (2, 3, 1, 1)),
+                                                 ((70, 1030), 1, None), ((50, 83), 1, None)])
+def test_krylov_product_fused_into_the_last_smoothing_pass(native, shape, npairs, sweeps):
+    """The trailing stage of k_sweep0m: v = A y and the dot products (v, r), (v, v) out of the cycle's last pass must be
+    what the separate operator kernel gives for the same y (odd row lengths take the separate kernel: fused is False)."""
+    mv = make_case("texture", shape, npairs, 21)
+    kw = dict(speed_alpha=1.0, remodelling_alpha=1e4)
+    if sweeps:
+        kw.update(nu_pre=sweeps[0], nu_post=sweeps[1], nu_pre_coarse=sweeps[2], nu_post_coarse=sweeps[3])
+    p = native.default_params(**kw)
+    rng = np.random.default_rng(3)
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        r = rng.standard_normal((npairs, 3) + s.level_shape(0))
+        y, v, dots, fused = s.debug_vcycle_apply(r)
+        assert fused == (s.level_shape(0)[1] % 2 == 0)
+        np.testing.assert_array_equal(y, s.debug_vcycle(r))                 # the cycle itself is unchanged, bit for bit
+        v_ref = s.debug_apply(0, y)
+        assert relerr(v, v_ref) < 1e-12      # same products, another order of summation
+        for k in range(npairs):
+            assert dots[k, 0] == pytest.approx(float(np.vdot(v_ref[k], r[k])), rel=1e-11, abs=1e-9 * np.linalg.norm(v_ref[k]) * np.linalg.norm(r[k]))
+            assert dots[k, 1] == pytest.approx(float(np.vdot(v_ref[k], v_ref[k])), rel=1e-12)
