@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-VOF_VERSION = 200                          # include/vof.h
+VOF_VERSION = 201                          # include/vof.h
 LIB = os.environ.get("VOF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "opticalflow_amd",
                                                 "csrc", "libvof.so")
 
@@ -23,7 +23,8 @@ class vof_params(C.Structure):             # include/vof.h: struct vof_params
                 ("coarse_precision", C.c_int32), ("vcycle_precision", C.c_int32), ("nu_pre_coarse", C.c_int32),
                 ("nu_post_coarse", C.c_int32), ("w_cycle_level", C.c_int32), ("w_cycle_visits", C.c_int32),
                 ("krylov_method", C.c_int32), ("gmres_restart", C.c_int32), ("fallback_after", C.c_int32),
-                ("warm_start_stride", C.c_int32)]
+                ("warm_start_stride", C.c_int32),
+                ("preconditioner", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class vof_pair_stats(C.Structure):         # include/vof.h: struct vof_pair_stats

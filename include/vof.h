@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 200 /* 0.2.0: vof_params carries its own size and the ABI version */
+#define VOF_VERSION 201 /* 0.2.1: vof_params carries its own size and the ABI version; + preconditioner */
 
 typedef struct vof_ctx vof_ctx;
 
@@ -65,6 +65,12 @@ typedef struct vof_params {
                                   constant initial fields, the others start from the solution of their nearest solved neighbour
                                   (the reference warm-starts pair k from pair k-1, OF.py:803-806).  Default 3; 0 or 1: every pair
                                   starts from the constant initial fields.  Same stopping rule either way */
+    int32_t preconditioner;    /* 0: multigrid cycle only; 1: direct - block-tridiagonal LU of the level-0 operator by image rows
+                                  (dense 3 n_j x 3 n_j Schur blocks, rocSOLVER; n_i (3 n_j)^2 doubles per pair in flight), the
+                                  reference's SuperLU branch (OF.py:1146-1147) as the preconditioner of the same Krylov iteration;
+                                  2 (default): the multigrid cycle, and the pairs it leaves unconverged once more with the direct
+                                  preconditioner when its buffers fit into the free device memory */
+    int32_t reserved0;         /* keeps the size a multiple of 8; must be 0 */
 } vof_params;
 
 /* Per-pair solver report (the reference prints these: OF.py:1131-1154). */
@@ -99,6 +105,9 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *   VOF_FUSE_RESTRICT=0        level 0: separate residual and restriction kernels
  *   VOF_FUSE_PROLONG=0         level 0: separate prolongation kernel instead of interpolating inside the first post-sweep
  *   VOF_SWEEP0=0               level 0: the generic fused sweep kernel instead of the dedicated k_sweep0
+ *   VOF_DIRECT_LU=own|rocsolver  direct preconditioner: dense inverse of the Schur blocks by the built-in kernel / by rocSOLVER
+ *                              (default: built-in up to 640 unknowns per image row, rocSOLVER - loaded on first use - beyond)
+ *   VOF_ROCSOLVER_LIB=path     rocSOLVER library to load
  *   VOF_FUSE_APPLY=0           the Krylov product after a cycle: separate operator kernel instead of the trailing stage of the
  *                              cycle's last smoothing pass
  *   VOF_SWEEP0M=0|1            level 0, float64 vectors: 0 = the 4-wave kernel k_sweep0; 1 = k_sweep0m with one sweep per pass

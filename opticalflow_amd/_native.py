@@ -26,7 +26,8 @@ class VofParams(C.Structure):
                 ("nu_pre", C.c_int32), ("nu_post", C.c_int32), ("reference_quirks", C.c_int32),
                 ("coarse_precision", C.c_int32), ("vcycle_precision", C.c_int32), ("nu_pre_coarse", C.c_int32), ("nu_post_coarse", C.c_int32),
                 ("w_cycle_level", C.c_int32), ("w_cycle_visits", C.c_int32), ("krylov_method", C.c_int32),
-                ("gmres_restart", C.c_int32), ("fallback_after", C.c_int32), ("warm_start_stride", C.c_int32)]
+                ("gmres_restart", C.c_int32), ("fallback_after", C.c_int32), ("warm_start_stride", C.c_int32),
+                ("preconditioner", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class VofPairStats(C.Structure):

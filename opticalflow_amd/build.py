@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvof.so")
 SOURCES = ["vof.hip"]
-DEPS = ["vof.hip", "vof_device.hpp", os.path.join("..", "..", "include", "vof.h")]
+DEPS = ["vof.hip", "vof_device.hpp", "vof_direct.hpp", os.path.join("..", "..", "include", "vof.h")]
 
 
 def needs_build():

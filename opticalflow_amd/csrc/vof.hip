@@ -7,7 +7,10 @@
 // operators; stopping rule ||b - A x|| <= rtol ||b|| (OF.py:1120,1126).  All frame pairs of a batch
 // advance together; per-pair scalars stay on the device.
 #include "vof_device.hpp"
+#include "vof_direct.hpp"
 #include "../../include/vof.h"
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -113,6 +116,13 @@ struct vof_ctx {
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     bool sweep0 = true;         // level 0: dedicated k_sweep0 kernel (VOF_SWEEP0=0: the generic k_sweep<SweepFine, GeoA>)
+    // direct preconditioner (block-tridiagonal LU by image rows, vof_direct.hpp); buffers allocated on first use
+    bool direct_on = false;          // the current batch is preconditioned by the direct solver instead of the multigrid cycle
+    int dir_cap = 0;                 // pairs the direct buffers hold
+    double *dir_T = nullptr, *dir_tabs = nullptr, *dir_W = nullptr, *dir_r = nullptr, *dir_y = nullptr, *dir_x = nullptr, *dir_t = nullptr;
+    int *dir_ipiv = nullptr, *dir_info = nullptr;
+    void* roc_handle = nullptr;      // rocblas_handle for rocSOLVER
+    long long direct_pairs = 0;      // pairs solved with the direct preconditioner since the context was created
     // Krylov product fused into the last smoothing pass of a cycle (k_sweep0m's trailing stage): requested by the Krylov loop
     // before the cycle, consumed by the final level-0 smoothing call if the fused path applies
     bool trail_enabled = true;  // VOF_FUSE_APPLY=0: always the separate operator kernel
@@ -603,9 +613,15 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
     return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/true, /*final_smooth=*/l == 0);
 }
 
+template <typename VT> int direct_apply_t(vof_ctx* c, VT* z, const VT* r, int np);   // direct preconditioner, below
+
 // One cycle M b -> *xslot (c->ky or c->kz).  The out-of-place sweeps may leave the result in the level-0 ping-pong partner
 // instead (an odd number of passes); the two buffers then trade places - a pointer swap instead of a copy of the vector.
 void vcycle(vof_ctx* c, double** xslot, const void* b, int np, const int* active) {
+    if (c->direct_on) {   // the direct preconditioner takes the place of the cycle (every pair of the batch, active or not)
+        VDISPATCH(c, direct_apply_t<VT>(c, (VT*)*xslot, (const VT*)b, np));
+        return;
+    }
     void* res = nullptr;
     VDISPATCH(c, res = (void*)vcycle_t<VT>(c, 0, (VT*)*xslot, (VT*)c->L[0].x2, (const VT*)b, np, active));
     if (res != (void*)*xslot) {
@@ -810,13 +826,159 @@ int gmres_phase(vof_ctx* c, int np, int* handed_over) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- direct preconditioner
+// rocSOLVER (dense LU + inverse of the m x m Schur blocks) is loaded on first use: the multigrid path has no such dependency.
+struct RocSolverApi {
+    void* lib = nullptr;
+    int (*create_handle)(void**) = nullptr;
+    int (*destroy_handle)(void*) = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*getrf)(void*, int, int, double*, int, long long, int*, long long, int*, int) = nullptr;
+    int (*getri)(void*, int, double*, int, long long, int*, long long, int*, int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        const char* names[] = {getenv("VOF_ROCSOLVER_LIB"), "librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so.0"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot load rocSOLVER: ") + (dlerror() ? dlerror() : "not found"); return false; }
+        create_handle = (int (*)(void**))dlsym(lib, "rocblas_create_handle");
+        destroy_handle = (int (*)(void*))dlsym(lib, "rocblas_destroy_handle");
+        set_stream = (int (*)(void*, hipStream_t))dlsym(lib, "rocblas_set_stream");
+        getrf = (int (*)(void*, int, int, double*, int, long long, int*, long long, int*, int))dlsym(lib, "rocsolver_dgetrf_strided_batched");
+        getri = (int (*)(void*, int, double*, int, long long, int*, long long, int*, int))dlsym(lib, "rocsolver_dgetri_strided_batched");
+        if (!create_handle || !destroy_handle || !set_stream || !getrf || !getri) { err = "rocSOLVER / rocBLAS symbols missing"; lib = nullptr; return false; }
+        return true;
+    }
+};
+RocSolverApi g_roc;
+
+// Dense inverse of the Schur blocks: the built-in Gauss-Jordan kernel (one workgroup per matrix) up to DIRECT_OWN_MAX
+// unknowns per image row, rocSOLVER getrf + getri beyond (VOF_DIRECT_LU=own|rocsolver forces one).
+constexpr int DIRECT_OWN_MAX = 640;
+bool direct_uses_rocsolver(const vof_ctx* c) {
+    if (const char* e = getenv("VOF_DIRECT_LU")) return e[0] == 'r';
+    return 3 * c->L[0].nj > DIRECT_OWN_MAX;
+}
+
+// device bytes the direct preconditioner needs per pair in flight
+size_t direct_bytes_per_pair(const vof_ctx* c) {
+    const size_t ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj;
+    return (ni * m * m + m * m + ni * nj * DIR_TAB + (3 * ni + 1) * m) * sizeof(double) + (m + 1) * sizeof(int);
+}
+
+// how many pairs the direct preconditioner can hold (0: it does not fit / is not available)
+int direct_capacity(vof_ctx* c, int want) {
+    if (c->dir_cap > 0) return c->dir_cap;
+    if (c->L.size() < 2 || c->L[0].C != nullptr) return 0;                      // one-level grids are solved directly anyway
+    if ((size_t)3 * c->L[0].nj > 8192) return 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    const double per = (double)direct_bytes_per_pair(c);
+    int fit = (int)std::min<double>(0.6 * (double)free_b / per, 1e6);
+    return std::max(0, std::min(fit, want));
+}
+
+int direct_alloc(vof_ctx* c, int pairs) {
+    if (c->dir_cap >= pairs) return 0;
+    if (c->dir_cap > 0) { c->err = "direct preconditioner buffers already allocated for a smaller batch"; return -3; }
+    const bool trace = getenv("VOF_TRACE") != nullptr;
+    const size_t ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj, P = (size_t)pairs;
+    if (direct_uses_rocsolver(c)) {
+        // (the library is ~0.9 GB: its first load on a machine can take minutes; the small blocks use the built-in kernel)
+        if (trace) { fprintf(stderr, "[vof] direct_alloc: loading rocSOLVER\n"); fflush(stderr); }
+        if (!g_roc.load()) { c->err = g_roc.err; return -3; }
+        if (trace) { fprintf(stderr, "[vof] direct_alloc: rocSOLVER loaded, allocating for %d pairs\n", pairs); fflush(stderr); }
+    }
+    if (int rc = dev_alloc(c, &c->dir_T, P * ni * m * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_W, P * m * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_tabs, P * ni * nj * DIR_TAB)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_r, P * ni * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_y, P * ni * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_x, P * ni * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_t, P * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_ipiv, P * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_info, P)) return rc;
+    if (direct_uses_rocsolver(c) && !c->roc_handle) {
+        if (trace) { fprintf(stderr, "[vof] direct_alloc: rocblas_create_handle\n"); fflush(stderr); }
+        if (g_roc.create_handle(&c->roc_handle) != 0) { c->err = "rocblas_create_handle failed"; return -2; }
+        if (g_roc.set_stream(c->roc_handle, c->stream) != 0) { c->err = "rocblas_set_stream failed"; return -2; }
+        if (trace) { fprintf(stderr, "[vof] direct_alloc: handle ready\n"); fflush(stderr); }
+    }
+    c->dir_cap = pairs;
+    return 0;
+}
+
+// factorisation for the current batch (frames / PairParam table as set up by solve_batch)
+int direct_setup(vof_ctx* c, int np) {
+    const vof_params& P = c->prm;
+    const int ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj;
+    const size_t sT = (size_t)ni * m * m, sW = (size_t)m * m, sTab = (size_t)ni * nj * DIR_TAB, rowTab = (size_t)nj * DIR_TAB;
+    hipStream_t s = c->stream;
+    Prof pr(c, VOF_K_COARSE_SETUP, 0);
+    k_dir_tables<<<dim3((nj + 255) / 256, ni, np), 256, 0, s>>>(c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha,
+                                                               P.reference_quirks, ni, nj, c->dir_tabs, c->pp);
+    const dim3 gm((m + 255) / 256, m, np);
+    const bool trace = getenv("VOF_TRACE") != nullptr;
+    for (int p = 0; p < ni; ++p) {
+        if (trace && (p < 2 || p == ni - 1)) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[vof] direct_setup: row %d of %d (m = %d, %d pairs)\n", p, ni, m, np); fflush(stderr); }
+        double* Tp = c->dir_T + (size_t)p * m * m;
+        if (p > 0) k_dir_W<<<gm, 256, 0, s>>>(Tp - (size_t)m * m, sT, c->dir_tabs + (size_t)(p - 1) * rowTab, sTab, nj, c->dir_W, sW);
+        k_dir_schur<<<gm, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, p > 0 ? c->dir_W : nullptr, sW, Tp, sT);
+        if (direct_uses_rocsolver(c)) {
+            if (g_roc.getrf(c->roc_handle, m, m, Tp, m, (long long)sT, c->dir_ipiv, (long long)m, c->dir_info, np) != 0 ||
+                g_roc.getri(c->roc_handle, m, Tp, m, (long long)sT, c->dir_ipiv, (long long)m, c->dir_info, np) != 0) {
+                c->err = "rocSOLVER getrf / getri failed";
+                return -2;
+            }
+        } else {
+            k_dir_invert<<<np, 1024, 2 * (size_t)m * sizeof(double), s>>>(Tp, sT, m, c->dir_ipiv, c->dir_info);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// z = A^{-1} r by block forward / backward substitution (r, z: level-0 vectors of the V-cycle type)
+template <typename VT>
+int direct_apply_t(vof_ctx* c, VT* z, const VT* r, int np) {
+    const int ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj;
+    const size_t sT = (size_t)ni * m * m, sTab = (size_t)ni * nj * DIR_TAB, rowTab = (size_t)nj * DIR_TAB, sV = (size_t)ni * m;
+    hipStream_t s = c->stream;
+    Prof pr(c, VOF_K_COARSE_SOLVE, 0);
+    const dim3 gp(64, np), gv((m + 255) / 256, np), gg((m + 63) / 64, np);
+    k_dir_permute<const VT, true><<<gp, 256, 0, s>>>(r, c->dir_r, ni, nj);
+    for (int p = 0; p < ni; ++p) {      // forward: y_p = r_p - L_p T_{p-1} y_{p-1}
+        if (p > 0) k_dir_gemv<<<gg, 256, 0, s>>>(c->dir_T + (size_t)(p - 1) * m * m, sT, m, c->dir_y + (size_t)(p - 1) * m, sV, c->dir_t, (size_t)m);
+        k_dir_rowupdate<<<gv, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, -1, c->dir_r + (size_t)p * m, sV,
+                                          p > 0 ? c->dir_t : nullptr, (size_t)m, c->dir_y + (size_t)p * m, sV);
+    }
+    for (int p = ni - 1; p >= 0; --p) {  // backward: x_p = T_p (y_p - U_p x_{p+1})
+        k_dir_rowupdate<<<gv, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, +1, c->dir_y + (size_t)p * m, sV,
+                                          p + 1 < ni ? c->dir_x + (size_t)(p + 1) * m : nullptr, sV, c->dir_t, (size_t)m);
+        k_dir_gemv<<<gg, 256, 0, s>>>(c->dir_T + (size_t)p * m * m, sT, m, c->dir_t, (size_t)m, c->dir_x + (size_t)p * m, sV);
+    }
+    k_dir_permute<VT, false><<<gp, 256, 0, s>>>(z, c->dir_x, ni, nj);
+    return 0;
+}
+
 int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double* vy, double* gm, double* speed,
                 vof_pair_stats* stats) {
     const vof_params& P = c->prm;
     // storage type of the cycle vectors for this batch (an earlier batch may have switched to float64: "auto"
     // precision after 8 iterations, GMRES fallback)
-    c->vfloat = P.vcycle_precision >= 1 && c->fused && c->L.size() > 1;
-    if (int rc = setup_batch(c, frames_dev, np)) return rc;
+    c->vfloat = P.vcycle_precision >= 1 && c->fused && c->L.size() > 1 && !c->direct_on;
+    if (c->direct_on) {   // direct preconditioner: block-tridiagonal LU instead of the Galerkin hierarchy
+        if (np > c->dir_cap) { c->err = "batch larger than the direct preconditioner's buffers"; return -1; }
+        c->frames = frames_dev;
+        c->npairs = np;
+        c->cur_units = np;
+        if (int rc = direct_setup(c, np)) return rc;
+        c->direct_pairs += np;
+    } else if (int rc = setup_batch(c, frames_dev, np)) return rc;
     Level& f = c->L[0];
     const size_t len = 3 * f.npts;
     hipStream_t s = c->stream;
@@ -980,6 +1142,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->gmres_restart < 0 || p->gmres_restart > GM_MAXM) { c->err = "gmres_restart must be in [0, 128]"; return -1; }
     if (p->fallback_after < 0) { c->err = "fallback_after must be >= 0"; return -1; }
     if (p->warm_start_stride < 0) { c->err = "warm_start_stride must be >= 0"; return -1; }
+    if (p->preconditioner < 0 || p->preconditioner > 2) { c->err = "preconditioner must be 0, 1 or 2"; return -1; }
     c->prm = *p;
     // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
     c->vfloat = p->vcycle_precision >= 1 && c->fused && c->L.size() > 1;
@@ -1020,6 +1183,7 @@ int vof_default_params(vof_params* p, size_t struct_size) {
     p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
     p->warm_start_stride = 3;      // vof_solve_stack_dev: every 3rd pair first, the others start from their solved neighbour
     p->fallback_after = 25;        // BiCGStab iterations before the fallback (the benchmark regimes need 3-17)
+    p->preconditioner = 2;         // multigrid cycle; pairs it leaves unconverged are re-solved with the direct preconditioner if it fits
     return 0;
 }
 
@@ -1265,23 +1429,82 @@ static int solve_stack_two_phase(vof_ctx* c, const double* movie, int P, double*
     return 0;
 }
 
+// Solve the listed pairs (frame index / output slot relative to `frames`, v_x ...) with the direct preconditioner, in batches
+// of what its buffers hold.  stats: per list entry.
+static int direct_solve_list(vof_ctx* c, const double* frames, const std::vector<PairParam>& items, double* v_x, double* v_y,
+                             double* remodelling, double* speed, vof_pair_stats* stats) {
+    if (items.empty()) return 0;
+    const int cap = direct_capacity(c, std::min<int>(c->B, (int)items.size()));
+    if (cap < 1) { c->err = "the direct preconditioner does not fit into the free device memory (3 n_j x 3 n_j doubles per image row and pair)"; return -3; }
+    if (int rc = direct_alloc(c, cap)) return rc;
+    if (!c->pp_buf) { if (int rc = dev_alloc(c, &c->pp_buf, (size_t)c->B)) return rc; }
+    std::vector<vof_pair_stats> st((size_t)c->dir_cap);
+    for (size_t o = 0; o < items.size(); o += (size_t)c->dir_cap) {
+        const int np = (int)std::min<size_t>((size_t)c->dir_cap, items.size() - o);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyAsync(c->pp_buf, items.data() + o, (size_t)np * sizeof(PairParam), hipMemcpyHostToDevice, c->stream));
+        c->pp = c->pp_buf;
+        c->direct_on = true;
+        int rc = solve_batch(c, frames, np, v_x, v_y, remodelling, speed, st.data());
+        c->direct_on = false;
+        c->pp = nullptr;
+        if (rc) return rc;
+        if (stats)
+            for (int i = 0; i < np; ++i) stats[o + i] = st[i];
+    }
+    return 0;
+}
+
 // Solve pairs 0 .. P-1 of a device-resident range of frames (P <= any size): two-phase warm start when it pays, plain
 // batches otherwise.  Outputs are indexed by the pair's position in the range.
+// preconditioner 1: every pair with the direct preconditioner; 2 (default): the multigrid cycle, and the pairs it leaves
+// unconverged (the grad-div dominated regimes) once more with the direct preconditioner if that fits.
 static int solve_range_dev(vof_ctx* c, const double* frames, int P, double* v_x, double* v_y, double* remodelling,
                            double* speed, vof_pair_stats* stats) {
-    const int stride = c->prm.warm_start_stride;
+    const vof_params prm = c->prm;
+    const int stride = prm.warm_start_stride;
     const size_t fs = frame_stride(c);
+    if (prm.preconditioner == 1 && c->L.size() > 1) {   // (a one-level grid is solved by its dense inverse anyway)
+        std::vector<PairParam> items((size_t)P);
+        for (int k = 0; k < P; ++k) items[k] = PairParam{prm.speed_alpha, prm.remodelling_alpha, k, k};
+        return direct_solve_list(c, frames, items, v_x, v_y, remodelling, speed, stats);
+    }
+    std::vector<vof_pair_stats> local;
+    if (!stats && prm.preconditioner == 2) { local.resize((size_t)P); stats = local.data(); }   // the fallback needs the flags
     // two phases double the latency-bound part of a solve (set-up, small coarse levels): worth it once the first phase
     // alone keeps the chip busy (>= 16 Mpixel of frame pairs; measured: 128^2 x 8 loses 45 %, 512^2 x 64 is neutral,
     // 1024^2 x 129 gains 22 %)
-    if (stride > 1 && P >= 2 * stride && (double)(P / stride) * (double)c->Ni * (double)c->Nj >= 16e6)
-        return solve_stack_two_phase(c, frames, P, v_x, v_y, remodelling, speed, stats, stride);
-    for (int k0 = 0; k0 < P; k0 += c->B) {
-        int np = std::min(c->B, P - k0);
-        int rc = solve_batch(c, frames + (size_t)k0 * fs, np, v_x + (size_t)k0 * fs, v_y + (size_t)k0 * fs,
-                             remodelling + (size_t)k0 * fs, speed ? speed + (size_t)k0 * fs : nullptr,
-                             stats ? stats + k0 : nullptr);
-        if (rc) return rc;
+    if (stride > 1 && P >= 2 * stride && (double)(P / stride) * (double)c->Ni * (double)c->Nj >= 16e6) {
+        if (int rc = solve_stack_two_phase(c, frames, P, v_x, v_y, remodelling, speed, stats, stride)) return rc;
+    } else {
+        for (int k0 = 0; k0 < P; k0 += c->B) {
+            int np = std::min(c->B, P - k0);
+            int rc = solve_batch(c, frames + (size_t)k0 * fs, np, v_x + (size_t)k0 * fs, v_y + (size_t)k0 * fs,
+                                 remodelling + (size_t)k0 * fs, speed ? speed + (size_t)k0 * fs : nullptr,
+                                 stats ? stats + k0 : nullptr);
+            if (rc) return rc;
+        }
+    }
+    if (prm.preconditioner == 2 && stats) {
+        std::vector<PairParam> items;
+        std::vector<int> which;
+        for (int k = 0; k < P; ++k)
+            if (!stats[k].converged && std::isfinite(stats[k].relative_residual)) {   // a NaN frame stays a reported failure
+                items.push_back(PairParam{prm.speed_alpha, prm.remodelling_alpha, k, k});
+                which.push_back(k);
+            }
+        if (!items.empty() && direct_capacity(c, 1) >= 1) {
+            std::vector<vof_pair_stats> st(items.size());
+            if (int rc = direct_solve_list(c, frames, items, v_x, v_y, remodelling, speed, st.data())) {
+                if (rc != -3) return rc;     // -3: no room / no rocSOLVER: keep the reported non-convergence
+                c->err.clear();
+            } else {
+                for (size_t i = 0; i < which.size(); ++i) {
+                    st[i].iterations += stats[which[i]].iterations;   // Krylov steps of both attempts
+                    stats[which[i]] = st[i];
+                }
+            }
+        }
     }
     return 0;
 }
@@ -1547,6 +1770,41 @@ int vof_subsample_dev(vof_ctx* c, const double* field, int n_fields, int box, in
     return 0;
 }
 
+// One batch of "virtual pairs" (own alpha / beta / frame / output slot each) of a device-resident movie, with the
+// preconditioner policy of solve_range_dev: direct only, or multigrid with the direct re-solve of what it leaves unconverged.
+static int solve_virtual_pairs(vof_ctx* c, const double* dmovie, const std::vector<PairParam>& hp, int np, double* const* outs,
+                               vof_pair_stats* st) {
+    if (c->prm.preconditioner == 1 && c->L.size() > 1) {
+        std::vector<PairParam> items(hp.begin(), hp.begin() + np);
+        return direct_solve_list(c, dmovie, items, outs[0], outs[1], outs[2], outs[3], st);
+    }
+    if (!c->pp_buf) { if (int rc = dev_alloc(c, &c->pp_buf, (size_t)c->B)) return rc; }
+    HIPCHK(hipStreamSynchronize(c->stream));   // hp is re-used by the caller: the previous upload must have completed
+    HIPCHK(hipMemcpyAsync(c->pp_buf, hp.data(), (size_t)np * sizeof(PairParam), hipMemcpyHostToDevice, c->stream));
+    c->pp = c->pp_buf;
+    int rc = solve_batch(c, dmovie, np, outs[0], outs[1], outs[2], outs[3], st);
+    c->pp = nullptr;
+    if (rc) return rc;
+    if (c->prm.preconditioner == 2) {
+        std::vector<PairParam> items;
+        std::vector<int> which;
+        for (int i = 0; i < np; ++i)
+            if (!st[i].converged && std::isfinite(st[i].relative_residual)) { items.push_back(hp[i]); which.push_back(i); }
+        if (!items.empty() && direct_capacity(c, 1) >= 1) {
+            std::vector<vof_pair_stats> s2(items.size());
+            int rc2 = direct_solve_list(c, dmovie, items, outs[0], outs[1], outs[2], outs[3], s2.data());
+            if (rc2 == 0) {
+                for (size_t i = 0; i < which.size(); ++i) { s2[i].iterations += st[which[i]].iterations; st[which[i]] = s2[i]; }
+            } else if (rc2 != -3) {
+                return rc2;
+            } else {
+                c->err.clear();
+            }
+        }
+    }
+    return 0;
+}
+
 int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, const vof_params* base,
                                  const double* speed_alphas, int n_sa, const double* remodelling_alphas, int n_ra,
                                  const double* blur_weights, int blur_radius, vof_variation_stats* out) {
@@ -1610,18 +1868,7 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
             for (int u = 0; u < g; ++u)
                 for (int k = 0; k < P; ++k)
                     hp[(size_t)u * P + k] = PairParam{speed_alphas[(t0 + u) / n_ra], remodelling_alphas[(t0 + u) % n_ra], k, u * P + k};
-            if (hipStreamSynchronize(c->stream) != hipSuccess) {   // hp is re-used: the previous upload must have completed
-                c->err = "stream synchronize failed";
-                return fail(-2);
-            }
-            if (hipMemcpyAsync(c->pp_buf, hp.data(), (size_t)np * sizeof(PairParam), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-                c->err = "H2D copy failed";
-                return fail(-2);
-            }
-            c->pp = c->pp_buf;
-            int rc = solve_batch(c, dmovie, np, c->st_out[0], c->st_out[1], c->st_out[2], c->st_out[3], st.data());
-            c->pp = nullptr;
-            if (rc) return fail(rc);
+            if (int rc = solve_virtual_pairs(c, dmovie, hp, np, c->st_out, st.data())) return fail(rc);
             for (int u = 0; u < g; ++u) {
                 Moments ms, mr;
                 if (int rc2 = chunk_moments(c, c->st_out[3] + (size_t)u * P * fs, (size_t)P * fs, &ms)) return fail(rc2);
@@ -1637,10 +1884,11 @@ int vof_vary_regularisation_host(vof_ctx* c, const double* movie, int n_frames, 
             q.remodelling_alpha = remodelling_alphas[t % n_ra];
             if (int rc = check_params(c, &q)) return fail(rc);
             Moments ms, mr;
+            std::vector<PairParam> hp2((size_t)c->B);
             for (int k0 = 0; k0 < P; k0 += c->B) {
                 int np = std::min(c->B, P - k0);
-                if (int rc = solve_batch(c, dmovie + (size_t)k0 * fs, np, c->st_out[0], c->st_out[1], c->st_out[2],
-                                         c->st_out[3], st.data() + k0)) return fail(rc);
+                for (int i = 0; i < np; ++i) hp2[i] = PairParam{q.speed_alpha, q.remodelling_alpha, k0 + i, i};
+                if (int rc = solve_virtual_pairs(c, dmovie, hp2, np, c->st_out, st.data() + k0)) return fail(rc);
                 if (int rc = chunk_moments(c, c->st_out[3], (size_t)np * fs, &ms)) return fail(rc);
                 if (int rc = chunk_moments(c, c->st_out[2], (size_t)np * fs, &mr)) return fail(rc);
             }

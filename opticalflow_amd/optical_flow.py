@@ -154,14 +154,15 @@ def _float64_copy(a, n_threads=4):
 
 def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                    use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
-                   multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None, warm_start_stride=None):
+                   multigrid_sweeps, w_cycle_level, krylov_method="auto", gmres_restart=None, warm_start_stride=None,
+                   preconditioner=None):
     """vof_params from the keyword arguments of ``variational_optical_flow``.  ``krylov_method`` may be a tuple
     ``("auto", fallback_after)``: BiCGStab iterations before GMRES takes over."""
     fallback_after = None
     if isinstance(krylov_method, (tuple, list)):
         krylov_method, fallback_after = krylov_method[0], int(krylov_method[1])
     if rtol is None:
-        rtol = 1e-11 if use_direct_solver else 1e-6
+        rtol = 1e-10 if use_direct_solver else 1e-6     # direct branch: the accuracy a sparse LU itself attains on these systems
     params = _native.default_params(
         speed_alpha=float(speed_alpha), remodelling_alpha=float(remodelling_alpha), delta_x=float(delta_x),
         delta_t=float(delta_t), initial_v_x=float(initial_v_x), initial_v_y=float(initial_v_y),
@@ -186,7 +187,17 @@ def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x
         params.fallback_after = fallback_after
     if warm_start_stride is not None:
         params.warm_start_stride = int(warm_start_stride)
+    if preconditioner is None:           # the reference's direct branch: the direct preconditioner (falls back if it cannot fit)
+        preconditioner = "direct" if use_direct_solver else "auto"
+    params.preconditioner = {"multigrid": 0, "direct": 1, "auto": 2}[preconditioner]
     return params
+
+
+def _direct_unavailable(exc):
+    """True if a native call failed only because the direct preconditioner cannot be used here (too large for the free
+    device memory, or no rocSOLVER): ``use_direct_solver=True`` then falls back to the multigrid path at rtol 1e-10."""
+    msg = str(exc)
+    return "direct preconditioner does not fit" in msg or "cannot load rocSOLVER" in msg or "rocSOLVER / rocBLAS symbols" in msg
 
 
 def variational_optical_flow(movie,
@@ -212,6 +223,7 @@ def variational_optical_flow(movie,
                              krylov_method="auto",
                              gmres_restart=None,
                              warm_start_stride=None,
+                             preconditioner=None,
                              verbose=False,
                              return_stats=False,
                              output="numpy",
@@ -229,8 +241,10 @@ def variational_optical_flow(movie,
       * all pairs are solved concurrently instead of warm-starting pair k from pair k-1 (OF.py:803-806): from the same
         constant initial guess, or (device-resident mode, large stacks) every 3rd pair first and the others from their
         solved neighbour; the converged answer is the same to solver tolerance;
-      * ``use_direct_solver=True`` (SuperLU in the reference, OF.py:1146-1147) is honoured as "solve
-        to rtol=1e-11" on the GPU;
+      * ``use_direct_solver=True`` (SuperLU in the reference, OF.py:1146-1147) selects the direct preconditioner - a
+        block-tridiagonal LU of the system by image rows on the GPU - inside the same Krylov iteration, converged to
+        rtol=1e-10 (one or two iterations); if its buffers (``n_i (3 n_j)^2`` doubles per pair) do not fit, the multigrid
+        path is run to rtol=1e-10 instead;
       * keyword-only extras: ``rtol`` (default 1e-6 = OF.py:1120), ``max_iterations`` (1000),
         ``reference_quirks`` (True keeps OF.py:698-699 'dy'=='dx' and the OF.py:1205
         ``speed_functional`` assignment), ``device``, ``max_pairs_in_flight``, ``coarse_precision`` (storage of the Galerkin
@@ -244,6 +258,9 @@ def variational_optical_flow(movie,
         ``krylov_method`` ("bicgstab": the reference's KSP type, OF.py:1081; "gmres": restarted GMRES with the same
         preconditioner and stopping rule; "auto" (default): BiCGStab, and GMRES(``gmres_restart``, default 100) for the
         pairs that have not converged after 25 iterations - the grad-div dominated regimes),
+        ``preconditioner`` ("auto" (default): the multigrid cycle, and pairs it leaves unconverged - the grad-div dominated
+        regimes, e.g. 8-bit data with ``speed_alpha`` below ~1e5 - are solved once more with the direct preconditioner when
+        that fits; "multigrid"; "direct"),
         ``warm_start_stride`` (both modes, stacks whose first phase fills the chip: every n-th pair of a batch is solved
         first, the others start from their solved neighbour, cf. OF.py:803-806; default 3, 0 = every pair from the
         constant initial fields),
@@ -258,7 +275,8 @@ def variational_optical_flow(movie,
                                                     speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y,
                                                     initial_remodelling, use_direct_solver, rtol, max_iterations,
                                                     reference_quirks, coarse_precision, vcycle_precision, multigrid_sweeps,
-                                                    w_cycle_level, krylov_method, gmres_restart, warm_start_stride), delta_x, delta_t)
+                                                    w_cycle_level, krylov_method, gmres_restart, warm_start_stride, preconditioner),
+                                                delta_x, delta_t)
     if output != "numpy":
         raise ValueError("output must be 'numpy' or 'torch'")
     movie = _float64_copy(np.asarray(movie))                           # OF.py:769
@@ -269,7 +287,7 @@ def variational_optical_flow(movie,
         raise ValueError("movie needs at least two frames")
     params = _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                             use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
-                            multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart, warm_start_stride)
+                            multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart, warm_start_stride, preconditioner)
     exact = max_pairs_in_flight is not None
     if max_pairs_in_flight is None and _solver is None:
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
@@ -281,7 +299,13 @@ def variational_optical_flow(movie,
             movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma, device=device, _solver=solver)
         else:
             movie_to_analyse = movie
-        v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+        try:
+            v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+        except _native.VofError as exc:
+            if not (use_direct_solver and preconditioner is None and _direct_unavailable(exc)):
+                raise
+            params.preconditioner = 2        # too large for the direct preconditioner: multigrid to the same tight tolerance
+            v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
     if verbose:
         m, s, ms = format_elapsed_time(time.time() - t0)
         print(f"Elapsed time for solve: {m} minutes, {s} seconds, {ms} milliseconds")
@@ -334,7 +358,13 @@ def _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_i
             solver.blur_dev(movie, movie_to_analyse, T, taps)
         else:
             movie_to_analyse = movie
-        stats = solver.solve_dev(movie_to_analyse, T, params, out[0], out[1], out[2], out[3])
+        try:
+            stats = solver.solve_dev(movie_to_analyse, T, params, out[0], out[1], out[2], out[3])
+        except _native.VofError as exc:
+            if params.preconditioner != 1 or not _direct_unavailable(exc):
+                raise
+            params.preconditioner = 2
+            stats = solver.solve_dev(movie_to_analyse, T, params, out[0], out[1], out[2], out[3])
     if verbose:
         print(f"iterations {stats['iterations'].tolist()}, converged {stats['converged'].astype(bool).tolist()}")
     result = dict(v_x=out[0], v_y=out[1], speed=out[3], remodelling=out[2], original_data=movie, delta_x=delta_x,
@@ -377,8 +407,8 @@ def vary_regularisation(movie,
     kw = dict(delta_x=1.0, delta_t=1.0, smoothing_sigma=None, initial_v_x=0.0, initial_v_y=0.0, initial_remodelling=0.0,
               use_direct_solver=False, rtol=None, max_iterations=1000, reference_quirks=True, device=0,
               max_pairs_in_flight=None, coarse_precision="bfloat16", vcycle_precision="float64", multigrid_sweeps=None,
-              w_cycle_level=None, krylov_method="auto", gmres_restart=None, warm_start_stride=None, verbose=False,
-              return_stats=False)
+              w_cycle_level=None, krylov_method="auto", gmres_restart=None, warm_start_stride=None, preconditioner=None,
+              verbose=False, return_stats=False)
     for k in kwargs:
         if k not in kw:
             raise TypeError(f"variational_optical_flow() got an unexpected keyword argument {k!r}")
@@ -387,14 +417,21 @@ def vary_regularisation(movie,
                             kw["initial_remodelling"], kw["use_direct_solver"], kw["rtol"], kw["max_iterations"],
                             kw["reference_quirks"], kw["coarse_precision"], kw["vcycle_precision"],
                             kw["multigrid_sweeps"], kw["w_cycle_level"], kw["krylov_method"], kw["gmres_restart"],
-                            kw["warm_start_stride"])       # accepted for signature parity; the sweep batches combinations
+                            kw["warm_start_stride"], kw["preconditioner"])   # warm_start_stride: accepted for signature parity
     taps = None if kw["smoothing_sigma"] is None else gaussian_taps(kw["smoothing_sigma"])
     # short movies: several combinations share one batch as "virtual pairs" (see vof_vary_regularisation_host)
     n_comb = max(1, len(speed_alpha_values) * len(remodelling_alpha_values))
     pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, (T - 1) * n_comb, kw["device"])
     with _device_context(N_i, N_j, pairs, kw["device"], kw["max_pairs_in_flight"] is not None) as solver:
-        rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,
-                                              remodelling_alpha_values, taps)
+        try:
+            rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,
+                                                  remodelling_alpha_values, taps)
+        except _native.VofError as exc:
+            if not (kw["use_direct_solver"] and kw["preconditioner"] is None and _direct_unavailable(exc)):
+                raise
+            params.preconditioner = 2
+            rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,
+                                                  remodelling_alpha_values, taps)
     if kw["verbose"]:
         for i, a in enumerate(speed_alpha_values):
             for j, b in enumerate(remodelling_alpha_values):

@@ -196,7 +196,8 @@ def test_identical_frames_give_zero_flow(of):
 def test_nonconvergence_is_reported_not_raised(of):
     """max_iterations=1 cannot reach 1e-12: the reference only prints a warning (OF.py:1135-1138)."""
     movie = orc.make_texture_stack(64, 2, seed=2)
-    res = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-13, max_iterations=1, return_stats=True)
+    res = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-13, max_iterations=1, return_stats=True,
+                                      preconditioner="multigrid")
     assert res["converged"] is False
     assert res["stats"]["iterations"][0] == 1
     assert np.isfinite(res["v_x"]).all()
@@ -460,3 +461,54 @@ def test_reference_side_binding_runs_on_g1():
     for arr, key in zip(out[:3], ("v_x", "v_y", "remodelling")):
         assert relerr(arr, g[key]) < LOOSE, key
     np.testing.assert_allclose(out[3], np.sqrt(out[0] ** 2 + out[1] ** 2), rtol=1e-14)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Direct preconditioner (block-tridiagonal LU by image rows): use_direct_solver=True and the robust fallback
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", GOLDEN + ["g6_8bit_64.npz"])
+def test_direct_preconditioner_against_reference_fixtures(of, name):
+    """preconditioner="direct": the reference's own direct-solver outputs are reproduced in one or two Krylov steps."""
+    g = load_golden(name)
+    res = of.variational_optical_flow(g["movie"], rtol=1e-10, preconditioner="direct", return_stats=True, **golden_kwargs(g))
+    st = res["stats"]
+    assert st["converged"].all() and st["iterations"].max() <= 3, st
+    check_fields(res, g, 2e-6 if "8bit" in name else TIGHT)
+
+
+@pytest.mark.parametrize("n,alpha,beta,scale", [(66, 1e4, 1e2, 255.0), (130, 1e4, 1e2, 255.0), (98, 2e3, 1.0, 255.0),
+                                                (130, 0.1, 1e2, 1.0), (66, 0.3, 0.1, 255.0)])
+def test_hard_regimes_are_rescued_by_the_direct_preconditioner(of, n, alpha, beta, scale):
+    """The grad-div dominated regimes (8-bit data with speed_alpha <~ 1e5), where the multigrid cycle
+    needs 40-200+ iterations or stagnates: with the default preconditioner="auto" every pair ends converged (re-solved with
+    the direct preconditioner where necessary), and the answer is the reference system's exact solution (oracle, SuperLU)."""
+    movie = orc.make_texture_stack(n, 3, seed=5) * scale
+    res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, rtol=1e-9, max_iterations=60,
+                                      return_stats=True)
+    st = res["stats"]
+    assert st["converged"].all() and st["relative_residual"].max() <= 1e-9, st
+    ref = orc.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta)
+    check_fields(res, ref, 1e-5)
+    # and the reference's own switch
+    res2 = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, use_direct_solver=True, return_stats=True)
+    assert res2["stats"]["converged"].all() and res2["stats"]["iterations"].max() <= 4
+    check_fields(res2, ref, 1e-6)
+
+
+def test_parameter_sweep_of_the_reference_script_on_8bit_data(of):
+    """AVOF.py:608-615: vary_regularisation over logspace(-1, 4) x logspace(-1, 4) on a down-sampled 8-bit stack with
+    smoothing_sigma=1 and use_direct_solver=True - almost all of that grid lies in the regimes the multigrid cycle does not
+    handle.  Every combination must come back converged and equal to the oracle's direct solve."""
+    movie = (orc.make_texture_stack(56, 2, seed=9) * 255).astype(np.uint8)
+    sa, ra = np.logspace(-1, 4, 6), np.logspace(-1, 4, 4)
+    r = of.vary_regularisation(movie, speed_alpha_values=sa, remodelling_alpha_values=ra, smoothing_sigma=1, use_direct_solver=True,
+                               delta_x=0.4, delta_t=10.0, return_stats=True)
+    assert r["stats"]["converged_all"].all(), r["stats"]["max_relative_residual"]
+    ref = orc.vary_regularisation(movie, sa, ra, smoothing_sigma=1, delta_x=0.4, delta_t=10.0)
+    for k in ("speed_means", "speed_variances", "remodelling_means", "remodelling_variances", "functional"):
+        np.testing.assert_allclose(r[k], ref[k], rtol=1e-6, atol=1e-12, err_msg=k)
+    # default policy (multigrid first, direct for what it leaves unconverged) gives the same tables at the reference's rtol
+    r2 = of.vary_regularisation(movie, speed_alpha_values=sa, remodelling_alpha_values=ra, smoothing_sigma=1, delta_x=0.4, delta_t=10.0,
+                                max_iterations=80, return_stats=True)
+    assert r2["stats"]["converged_all"].all()
+    np.testing.assert_allclose(r2["speed_means"], ref["speed_means"], rtol=2e-3)
