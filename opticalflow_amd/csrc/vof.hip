@@ -836,6 +836,15 @@ struct RocSolverApi {
     int (*getrf)(void*, int, int, double*, int, long long, int*, long long, int*, int) = nullptr;
     int (*getri)(void*, int, double*, int, long long, int*, long long, int*, int) = nullptr;
     std::string err;
+    // already in the process (loaded by us earlier, or e.g. by PyTorch)?  Then using it costs nothing; a first load of the
+    // ~0.9 GB library can take minutes on a machine that has never read it.
+    bool resident() {
+        if (lib) return true;
+        const char* names[] = {"librocsolver.so.0", "librocsolver.so"};
+        for (const char* n : names)
+            if (void* h = dlopen(n, RTLD_NOLOAD | RTLD_LAZY)) { dlclose(h); return true; }
+        return false;
+    }
     bool load() {
         if (lib) return true;
         const char* names[] = {getenv("VOF_ROCSOLVER_LIB"), "librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so.0"};
@@ -862,6 +871,15 @@ constexpr int DIRECT_OWN_MAX = 640;
 bool direct_uses_rocsolver(const vof_ctx* c) {
     if (const char* e = getenv("VOF_DIRECT_LU")) return e[0] == 'r';
     return 3 * c->L[0].nj > DIRECT_OWN_MAX;
+}
+
+// The automatic re-solve (preconditioner 2) must not stall a call for minutes behind a library load nobody asked for: it
+// uses rocSOLVER only if that is resident already (or forced by VOF_DIRECT_LU); the built-in kernel is always available.
+int direct_capacity(vof_ctx* c, int want);
+bool direct_ok_for_fallback(vof_ctx* c) {
+    if (direct_capacity(c, 1) < 1) return false;
+    if (!direct_uses_rocsolver(c)) return true;
+    return getenv("VOF_DIRECT_LU") != nullptr || g_roc.resident();
 }
 
 // device bytes the direct preconditioner needs per pair in flight
@@ -1493,7 +1511,7 @@ static int solve_range_dev(vof_ctx* c, const double* frames, int P, double* v_x,
                 items.push_back(PairParam{prm.speed_alpha, prm.remodelling_alpha, k, k});
                 which.push_back(k);
             }
-        if (!items.empty() && direct_capacity(c, 1) >= 1) {
+        if (!items.empty() && direct_ok_for_fallback(c)) {
             std::vector<vof_pair_stats> st(items.size());
             if (int rc = direct_solve_list(c, frames, items, v_x, v_y, remodelling, speed, st.data())) {
                 if (rc != -3) return rc;     // -3: no room / no rocSOLVER: keep the reported non-convergence
@@ -1790,7 +1808,7 @@ static int solve_virtual_pairs(vof_ctx* c, const double* dmovie, const std::vect
         std::vector<int> which;
         for (int i = 0; i < np; ++i)
             if (!st[i].converged && std::isfinite(st[i].relative_residual)) { items.push_back(hp[i]); which.push_back(i); }
-        if (!items.empty() && direct_capacity(c, 1) >= 1) {
+        if (!items.empty() && direct_ok_for_fallback(c)) {
             std::vector<vof_pair_stats> s2(items.size());
             int rc2 = direct_solve_list(c, dmovie, items, outs[0], outs[1], outs[2], outs[3], s2.data());
             if (rc2 == 0) {
