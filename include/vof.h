@@ -227,6 +227,9 @@ int vof_debug_sweep(vof_ctx* ctx, int level, double* x_host, const double* b_hos
 int vof_debug_smooth(vof_ctx* ctx, int level, double* x_host, const double* b_host, int nu, int reverse, int from_zero);
 int vof_debug_restrict(vof_ctx* ctx, int level, const double* fine_host, double* coarse_host);
 int vof_debug_prolong_add(vof_ctx* ctx, int level, double* fine_host, const double* coarse_host);
+/* stored level >= 1: coarse right-hand side R (b - A x_new) straight after ONE forward sweep x_old -> x_new with right-hand
+ * side b (x_old_host NULL: the sweep started from zero), computed from the sweep's update alone (k_resrestrict_u) */
+int vof_debug_resrestrict_u(vof_ctx* ctx, int level, const double* x_new_host, const double* x_old_host, double* coarse_host);
 int vof_debug_stencil(vof_ctx* ctx, int level, double* c_host); /* [pair][81][n_i][n_j], level >= 1 */
 int vof_debug_vcycle(vof_ctx* ctx, const double* r_host, double* e_host);
 int vof_debug_coarse_solve(vof_ctx* ctx, const double* r_host, double* e_host);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "vof_debug_smooth": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "vof_set_fused_sweeps": (C.c_int, [_vp, C.c_int]),
     "vof_debug_restrict": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "vof_debug_resrestrict_u": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "vof_debug_prolong_add": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "vof_debug_stencil": (C.c_int, [_vp, C.c_int, _vp]),
     "vof_debug_vcycle": (C.c_int, [_vp, _vp, _vp]),
@@ -382,6 +383,15 @@ class Solver:
         fine = np.ascontiguousarray(fine, dtype=np.float64).reshape(self._vec(level))
         coarse = np.empty(self._vec(level + 1))
         self._check(self.lib.vof_debug_restrict(self.h, level, _ptr(fine), _ptr(coarse)), "debug_restrict")
+        return coarse
+
+    def debug_resrestrict_u(self, level, x_new, x_old=None):
+        x_new = np.ascontiguousarray(x_new, dtype=np.float64).reshape(self._vec(level))
+        if x_old is not None:
+            x_old = np.ascontiguousarray(x_old, dtype=np.float64).reshape(self._vec(level))
+        coarse = np.empty(self._vec(level + 1))
+        self._check(self.lib.vof_debug_resrestrict_u(self.h, level, _ptr(x_new), _ptr(x_old) if x_old is not None else None,
+                                                     _ptr(coarse)), "debug_resrestrict_u")
         return coarse
 
     def debug_prolong_add(self, level, fine, coarse):

@@ -114,6 +114,8 @@ struct vof_ctx {
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
     bool fuse_prolong = true;   // level 0: coarse-grid correction interpolated inside the first post-sweep
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
+    bool fuse_resu = true;      // stored levels: coarse right-hand side from the last pre-smoothing sweep's update (k_resrestrict_u;
+                                // VOF_FUSE_RESU=0: stand-alone residual + restriction kernels)
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
     bool sweep0 = true;         // level 0: dedicated k_sweep0 kernel (VOF_SWEEP0=0: the generic k_sweep<SweepFine, GeoA>)
     // direct preconditioner (block-tridiagonal LU by image rows, vof_direct.hpp); buffers allocated on first use
@@ -378,6 +380,27 @@ void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, VT* bc, int np, co
         c->prm.reference_quirks, x, b, bc, k.ni, k.nj, active, c->pp);
 }
 
+// stored level l >= 1, straight after ONE forward Gauss-Seidel sweep x_old -> x_new (x_old == nullptr: from zero): the coarse
+// right-hand side b_{l+1} = R (b - A x_new) from the sweep's update alone (k_resrestrict_u) - no b, no diagonal blocks, half
+// of the off-diagonal coefficients, no residual vector in HBM
+inline double resu_coef_bytes(const vof_ctx* c) {   // average per fine point: 8 + 6 + 2 + 0 neighbour blocks over the four colours
+    return c->cfmt == 2 ? 18.5 * 4 : (c->cfmt == 1 ? 36.0 * 4 : 36.0 * 8);
+}
+template <typename VT>
+void resrestrict_u_t(vof_ctx* c, int l, const VT* x_new, const VT* x_old, VT* bc, int np, const int* active) {
+    Level &f = c->L[l], &k = c->L[l + 1];
+    const double vs = sizeof(VT);
+    // algorithmic: the residual and the restriction it performs (as apply_stored_t + restrict_level_t count them)
+    const double algo = (coef_bytes(c, l) + 9.0 * vs) * f.npts + 3.0 * vs * (f.npts + k.npts);
+    const double moved = (resu_coef_bytes(c) + (x_old ? 6.0 : 3.0) * vs) * f.npts + 3.0 * vs * k.npts;
+    Prof p(c, VOF_K_RESIDUAL, l, algo, moved);
+    dim3 g(1, (k.ni + BY - 1) / BY, np);
+    CDISPATCH(c, l, {
+        if (x_old) k_resrestrict_u<CT, VT, true><<<g, blk2d, 0, c->stream>>>((const CW*)f.C, f.ni, f.nj, x_new, x_old, bc, k.ni, k.nj, active);
+        else k_resrestrict_u<CT, VT, false><<<g, blk2d, 0, c->stream>>>((const CW*)f.C, f.ni, f.nj, x_new, x_old, bc, k.ni, k.nj, active);
+    });
+}
+
 template <typename VT>
 void prolong_add_level_t(vof_ctx* c, int l, VT* fine, const VT* coarse, int np, const int* active) {
     Level &f = c->L[l], &k = c->L[l + 1];
@@ -592,9 +615,20 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
     Level& nx = c->L[l + 1];
     const int nu1 = (l > 0 && c->prm.nu_pre_coarse > 0) ? c->prm.nu_pre_coarse : c->prm.nu_pre;
     const int nu2 = (l > 0 && c->prm.nu_post_coarse > 0) ? c->prm.nu_post_coarse : c->prm.nu_post;
-    // pre-smoothing (result forced into x: the residual / post-smoothing below read x)
-    smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active);
-    if (l == 0 && lv.C == nullptr && c->stream_apply && c->fuse_restrict) {
+    // pre-smoothing.  Level 0: result forced into x (the Krylov loop owns that buffer).  Stored levels: the result may end in
+    // the ping-pong partner (the caller only reads the buffer this function returns), so the two just trade names - and the
+    // partner then still holds the input of the last sweep, which is all k_resrestrict_u needs besides the result.
+    const bool resu = l > 0 && lv.C != nullptr && c->fused && c->fuse_resu && nu1 >= 1;
+    if (l > 0 && c->fused) {
+        VT* xr = smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active, nullptr, /*allow_swap=*/true);
+        if (xr != x) std::swap(x, tmp);
+    } else {
+        smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active);
+    }
+    if (resu) {
+        const VT* x_old = (from_zero && nu1 == 1) ? nullptr : tmp;
+        resrestrict_u_t<VT>(c, l, x, x_old, (VT*)nx.b, np, active);
+    } else if (l == 0 && lv.C == nullptr && c->stream_apply && c->fuse_restrict) {
         resrestrict_fine_t<VT>(c, x, b, (VT*)nx.b, np, active);
     } else {
         apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
@@ -1287,6 +1321,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_STREAM_APPLY")) c->stream_apply = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_RESTRICT")) c->fuse_restrict = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
+    if (const char* e = getenv("VOF_FUSE_RESU")) c->fuse_resu = e[0] != '0';
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';
@@ -2176,6 +2211,17 @@ int vof_debug_restrict(vof_ctx* c, int level, const double* fine_host, double* c
     Level& k = c->L[level + 1];
     if (int rc = dbg_up(c, c->kp, fine_host, nbytes / sizeof(double))) return rc;
     VDISPATCH(c, restrict_level_t<VT>(c, level, (const VT*)c->kp, (VT*)c->kv, c->npairs, nullptr));
+    return dbg_down(c, coarse_host, c->kv, (size_t)c->npairs * 3 * k.npts);
+}
+
+int vof_debug_resrestrict_u(vof_ctx* c, int level, const double* x_new_host, const double* x_old_host, double* coarse_host) {
+    DBG_LEVEL(level)
+    if (level < 1 || level + 1 >= (int)c->L.size() || !lv.C) { c->err = "a stored level with a coarser level is needed"; return -1; }
+    Level& k = c->L[level + 1];
+    if (int rc = dbg_up(c, c->kp, x_new_host, nbytes / sizeof(double))) return rc;
+    if (x_old_host)
+        if (int rc = dbg_up(c, c->kt, x_old_host, nbytes / sizeof(double))) return rc;
+    VDISPATCH(c, resrestrict_u_t<VT>(c, level, (const VT*)c->kp, x_old_host ? (const VT*)c->kt : (const VT*)nullptr, (VT*)c->kv, c->npairs, nullptr));
     return dbg_down(c, coarse_host, c->kv, (size_t)c->npairs * 3 * k.npts);
 }
 

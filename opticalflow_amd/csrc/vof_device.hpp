@@ -99,6 +99,12 @@ template <typename CT> struct CoefSet {
 #pragma unroll
         for (int k = 0; k < PLANES; ++k) w[k] = sp[(size_t)k * plane];
     }
+    // (wave-uniform base pointer) + (32-bit lane index): the plane offsets stay in scalar registers and every load takes the
+    // "saddr + voffset" form instead of a 64-bit per-lane address per plane
+    __device__ __forceinline__ void load_u(const word_t* __restrict__ ubase, size_t plane, unsigned idx) {
+#pragma unroll
+        for (int k = 0; k < PLANES; ++k) w[k] = (ubase + (size_t)k * plane)[idx];
+    }
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int k = 0; k < PLANES; ++k) w[k] = 0;
@@ -555,6 +561,182 @@ __global__ __launch_bounds__(NT) void k_prolong_add(VT* __restrict__ fine, int n
     f[idx] = (VT)((double)f[idx] + s0);
     f[nf + idx] = (VT)((double)f[nf + idx] + s1);
     f[2 * nf + idx] = (VT)((double)f[2 * nf + idx] + s2);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resrestrict_u: coarse right-hand side b_c = R (b - A x_new) of a STORED level straight after one 4-colour Gauss-Seidel
+// sweep x_old -> x_new (colour order 0, 1, 2, 3), without b, without the diagonal blocks and with half of the off-diagonal
+// coefficients.
+//
+// A sweep solves, point by point, D_i x_i = b_i - sum_{j != i} A_ij x_j with the neighbour values current at that
+// moment, so the residual left at point i when the sweep is over is due to the neighbours updated AFTER i alone:
+//     r_i = b_i - (A x_new)_i = - sum_{j later than i} A_ij (x_new - x_old)_j            (x_old = 0: sweep from zero)
+// Colour 3 (odd row, odd column) has no later neighbour: r = 0.  Colour 2 (odd row, even column): its left / right
+// neighbours (colour 3).  Colour 1 (even row, odd column): the six neighbours in the rows above and below (colours 2, 3).
+// Colour 0: all eight.  In the colour-split bfloat16 format that is 36 / 28 / 10 / 0 words per point = 74 B per point on
+// average instead of the 180 B + b + the r round trip of the stand-alone residual and restriction kernels:
+// 74 + 3 s (+ 3 s for x_old) in, 0.75 s out per fine point instead of 180 + 9 s + 3.75 s.
+//
+// One wave per coarse row; lane <-> coarse column of a 64-column chunk, the wave walks along the row and carries the
+// colour-1 residual of its last column into the next chunk (the only value a coarse point needs from its left neighbour's
+// lane).  No LDS, no barrier.  Same weights as k_restrict (R = P^T / 4, the orphan last odd row / column has weight 1).
+// ------------------------------------------------------------------------------------------
+// Loads are written as (wave-uniform base pointer) + (32-bit lane index): the uniform part - pair, plane, colour class, row -
+// stays in scalar registers and every load takes the "saddr + voffset" form; with per-lane 64-bit pointers the ~140 addresses
+// of a chunk alone needed more vector registers than the data.
+template <typename CT, unsigned DMASK>   // load the coefficient words / planes of the neighbour blocks d with bit d of DMASK set
+__device__ __forceinline__ void coef_load_blocks(CoefSet<CT>& cs, const typename CoefFmt<CT>::word_t* __restrict__ rowbase,
+                                                 size_t plane, unsigned col, bool ok) {
+    if constexpr (std::is_same<CT, CoefB16>::value) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {   // word k holds the off-diagonal coefficients 2k, 2k + 1 (blocks dd = j / 9, d = dd + (dd >= 4))
+            const int dd0 = (2 * k) / 9, dd1 = (2 * k + 1) / 9;
+            const int d0 = dd0 < 4 ? dd0 : dd0 + 1, d1 = dd1 < 4 ? dd1 : dd1 + 1;
+            if (((DMASK >> d0) & 1u) || ((DMASK >> d1) & 1u)) cs.w[k] = ok ? (rowbase + (size_t)k * plane)[col] : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 9; ++d)
+            if ((DMASK >> d) & 1u) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) cs.w[d * 9 + e] = ok ? (rowbase + (size_t)(d * 9 + e) * plane)[col] : (typename CoefFmt<CT>::word_t)0;
+            }
+    }
+}
+
+// The colour phases are independent, so the compiler would hoist all ~140 loads of a chunk to its top (240-256 registers or
+// spills); a compiler + scheduling fence between the phases keeps one phase's coefficient words live at a time.
+// Register budget (launch bound, waves per SIMD): 4 for the packed bfloat16 stencils (104-113 registers; 3 with float64
+// vectors and x_old, which would spill a few), 2 for the float32 / float64 formats (72 coefficient words for colour 0).
+template <typename CT, typename VT, bool HAS_OLD> struct ResuBudget {
+    static constexpr int kMinWaves = !std::is_same<CT, CoefB16>::value ? 2 : ((HAS_OLD && sizeof(VT) == 8) ? 3 : 4);
+};
+#ifdef RESU_NO_FENCE
+#define RESU_PHASE_FENCE() do {} while (0)
+#else
+#define RESU_PHASE_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+template <typename CT, typename VT, bool HAS_OLD>
+__global__ __launch_bounds__(NT, (ResuBudget<CT, VT, HAS_OLD>::kMinWaves)) void k_resrestrict_u(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj,
+                                                      const VT* __restrict__ x_new, const VT* __restrict__ x_old,
+                                                      VT* __restrict__ bc, int nci, int ncj, const int* __restrict__ active) {
+    typedef typename CoefFmt<CT>::word_t word_t;
+    const int pair = blockIdx.z;
+    if (active && !active[pair]) return;
+    const int cp = blockIdx.y * BY + __builtin_amdgcn_readfirstlane(threadIdx.y);     // one wave per coarse row (wave-uniform)
+    if (cp >= nci) return;
+    const int lane = threadIdx.x;
+    const size_t npts = (size_t)ni * nj, nc = (size_t)nci * ncj;
+    const CLay L(ni, nj);
+    const word_t* Cp = C + (size_t)pair * CoefFmt<CT>::PLANES * L.plane;
+    const VT* xn = x_new + (size_t)pair * 3 * npts;
+    const VT* xo = HAS_OLD ? x_old + (size_t)pair * 3 * npts : nullptr;
+    VT* out = bc + (size_t)pair * 3 * nc + (size_t)cp * ncj;
+    const int fp = 2 * cp;
+    const bool rowU = fp - 1 >= 0, rowD = fp + 1 < ni;
+    const double wiU = 0.5, wiD = (cp + 1 < nci) ? 0.5 : 1.0;
+    // uniform row bases: coefficient rows of the colour classes 0, 1 (row fp), 2 (rows fp - 1, fp + 1), x rows fp - 1 .. fp + 1
+    const word_t* c0row = Cp + (size_t)cp * L.hj;
+    const word_t* c1row = Cp + L.sub + (size_t)cp * L.hj;
+    const word_t* c2rowU = Cp + 2 * L.sub + (size_t)(rowU ? cp - 1 : 0) * L.hj;
+    const word_t* c2rowD = Cp + 2 * L.sub + (size_t)cp * L.hj;
+    const size_t xrow[3] = {(size_t)(rowU ? fp - 1 : 0) * nj, (size_t)fp * nj, (size_t)(rowD ? fp + 1 : 0) * nj};
+    const bool xrok[3] = {rowU, true, rowD};
+    double carry0 = 0.0, carry1 = 0.0, carry2 = 0.0;   // colour-1 residual of the column left of the chunk (wave-uniform)
+    for (int cq0 = 0; cq0 < ncj; cq0 += BX) {
+        const int cq = cq0 + lane, fq = 2 * cq;
+        const bool on = cq < ncj;
+        const unsigned ucq = on ? (unsigned)cq : 0u;
+        // delta = x_new - x_old at rows fp - 1 .. fp + 1 (a = 0..2), columns fq - 1 .. fq + 2 (c = 0..3); 0 outside the grid
+        // (row fp is only needed at columns fq - 1 and fq + 1: its even columns are colour 0, never "later").  Loaded column
+        // group by column group, just before the phase that needs it first, to keep the register footprint at 128.
+        double dl[3][4][3];
+        auto load_col = [&](const int cc, const bool with_mid) {
+            const int q = fq + cc - 1;
+            const bool qok = on && q >= 0 && q < nj;
+            const unsigned uq = qok ? (unsigned)q : 0u;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (a == 1 && !with_mid) continue;
+                const bool ok = qok && xrok[a];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    double v = (double)(xn + (size_t)f * npts + xrow[a])[uq];
+                    if (HAS_OLD) v -= (double)(xo + (size_t)f * npts + xrow[a])[uq];
+                    dl[a][cc][f] = ok ? v : 0.0;
+                }
+            }
+        };
+        // ---- colour 1 at (fp, fq + 1): the three neighbours above and the three below (columns fq .. fq + 2)
+        load_col(1, false); load_col(2, true); load_col(3, false);
+        double acc0, acc1, acc2;   // 4 x the coarse value
+        {
+            double r10 = 0.0, r11 = 0.0, r12 = 0.0;
+            CoefSet<CT> cs;
+            coef_load_blocks<CT, 0x1C7u>(cs, c1row, L.plane, ucq, on && fq + 1 < nj);
+#pragma unroll
+            for (int a = 0; a < 3; a += 2)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int t0 = (a * 3 + b) * 9;
+                    const double xu = dl[a][b + 1][0], xw = dl[a][b + 1][1], xg = dl[a][b + 1][2];
+                    r10 -= cs.get(t0 + 0) * xu + cs.get(t0 + 1) * xw + cs.get(t0 + 2) * xg;
+                    r11 -= cs.get(t0 + 3) * xu + cs.get(t0 + 4) * xw + cs.get(t0 + 5) * xg;
+                    r12 -= cs.get(t0 + 6) * xu + cs.get(t0 + 7) * xw + cs.get(t0 + 8) * xg;
+                }
+            // the colour-1 residual of column fq - 1 belongs to the lane on the left (chunk edge: the carry)
+            double l0 = __shfl_up(r10, 1), l1 = __shfl_up(r11, 1), l2 = __shfl_up(r12, 1);
+            if (lane == 0) { l0 = carry0; l1 = carry1; l2 = carry2; }
+            carry0 = __shfl(r10, BX - 1); carry1 = __shfl(r11, BX - 1); carry2 = __shfl(r12, BX - 1);
+            const double wjR = (cq + 1 < ncj) ? 0.5 : 1.0;
+            acc0 = 0.5 * l0 + wjR * r10; acc1 = 0.5 * l1 + wjR * r11; acc2 = 0.5 * l2 + wjR * r12;
+        }
+        RESU_PHASE_FENCE();
+        // ---- colour 2 at (fp - 1, fq) and (fp + 1, fq): left and right neighbour of the same row
+        load_col(0, true);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int a = side ? 2 : 0;
+            CoefSet<CT> cs;
+            coef_load_blocks<CT, 0x028u>(cs, side ? c2rowD : c2rowU, L.plane, ucq, on && (side ? rowD : rowU));
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; b += 2) {
+                const int t0 = (3 + b) * 9;
+                const double xu = dl[a][b][0], xw = dl[a][b][1], xg = dl[a][b][2];
+                s0 -= cs.get(t0 + 0) * xu + cs.get(t0 + 1) * xw + cs.get(t0 + 2) * xg;
+                s1 -= cs.get(t0 + 3) * xu + cs.get(t0 + 4) * xw + cs.get(t0 + 5) * xg;
+                s2 -= cs.get(t0 + 6) * xu + cs.get(t0 + 7) * xw + cs.get(t0 + 8) * xg;
+            }
+            const double wi = side ? wiD : wiU;
+            acc0 += wi * s0; acc1 += wi * s1; acc2 += wi * s2;
+        }
+        RESU_PHASE_FENCE();
+        // ---- colour 0 at (fp, fq): all eight neighbour blocks
+        {
+            CoefSet<CT> cs;
+            coef_load_blocks<CT, 0x1EFu>(cs, c0row, L.plane, ucq, on);   // fq < nj always holds for cq < ncj
+            double r00 = 0.0, r01 = 0.0, r02 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (a == 1 && b == 1) continue;
+                    const int t0 = (a * 3 + b) * 9;
+                    const double xu = dl[a][b][0], xw = dl[a][b][1], xg = dl[a][b][2];
+                    r00 -= cs.get(t0 + 0) * xu + cs.get(t0 + 1) * xw + cs.get(t0 + 2) * xg;
+                    r01 -= cs.get(t0 + 3) * xu + cs.get(t0 + 4) * xw + cs.get(t0 + 5) * xg;
+                    r02 -= cs.get(t0 + 6) * xu + cs.get(t0 + 7) * xw + cs.get(t0 + 8) * xg;
+                }
+            acc0 += r00; acc1 += r01; acc2 += r02;
+        }
+        if (on) {
+            out[cq] = (VT)(0.25 * acc0);
+            out[nc + cq] = (VT)(0.25 * acc1);
+            out[2 * nc + cq] = (VT)(0.25 * acc2);
+        }
+        RESU_PHASE_FENCE();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1462,6 +1644,7 @@ struct SweepFine {
     static constexpr int kMinWaves = 1;
     struct cset_t { __device__ __forceinline__ void clear() {} };
     __device__ __forceinline__ void prefetch(const SweepCols&, size_t, int, cset_t&) const {}
+    __device__ __forceinline__ void prefetch_u(size_t, unsigned, int, cset_t&) const {}
 
     template <class G, typename VT>
     __device__ __forceinline__ void update(const SweepCols& cc, const SweepRows& rw, const VT* xs, const double* im,
@@ -1524,6 +1707,10 @@ struct SweepStored {
     typedef CoefSet<CT> cset_t;
     __device__ __forceinline__ void prefetch(const SweepCols& cc, size_t rowpart, int pair, cset_t& cf) const {
         cf.load(C + (size_t)pair * CoefFmt<CT>::PLANES * plane + rowpart + cc.cq, plane);
+    }
+    // urow: wave-uniform part of the index (row / colour class), idx: the lane's part
+    __device__ __forceinline__ void prefetch_u(size_t urow, unsigned idx, int pair, cset_t& cf) const {
+        cf.load_u(C + (size_t)pair * CoefFmt<CT>::PLANES * plane + urow, plane, idx);
     }
 
     template <class G, typename VT>
@@ -1884,8 +2071,18 @@ __global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, i
         // (6) coefficient prefetch for the next step's point (stored float stencils)
         if (Pol::kPrefetch) {
             const int rrn = e + 2 + stage_row_off, pn = g.p0 + rrn;
+#ifdef SW_NO_SADDR
             if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)
                 pol.prefetch(cc, (size_t)((pn & 1) << 1) * L.sub + (size_t)(pn >> 1) * L.hj, pair, cf);
+#else
+            if (!G::HALO_WAVE || wave < 4) {   // colour waves: the row is wave-uniform -> scalar row / plane offsets
+                const int pnu = __builtin_amdgcn_readfirstlane(pn);
+                if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)
+                    pol.prefetch_u((size_t)((pnu & 1) << 1) * L.sub + (size_t)(pnu >> 1) * L.hj, (unsigned)cc.cq, pair, cf);
+            } else if (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni) {   // halo wave: a row per lane
+                pol.prefetch_u(0, (unsigned)((size_t)((pn & 1) << 1) * L.sub + (size_t)(pn >> 1) * L.hj + cc.cq), pair, cf);
+            }
+#endif
         }
         __syncthreads();
     }

@@ -238,6 +238,31 @@ def test_fused_sweep_on_stored_levels(native, kind, shape, npairs, alpha, beta, 
                 assert relerr(xg, xc) < 1e-13, (lvl, reverse)
 
 
+@pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", SWEEP_CASES[1:4] + [("texture", (300, 530), 1, 1.0, 1e4, 12)])
+@pytest.mark.parametrize("coarse_precision,vcycle_precision", [(0, 0), (1, 0), (2, 0), (2, 1)])
+def test_coarse_rhs_from_the_sweep_update(native, kind, shape, npairs, alpha, beta, seed, coarse_precision, vcycle_precision):
+    """k_resrestrict_u: after ONE forward sweep x_old -> x_new the residual is -U (x_new - x_old) (U = couplings to the
+    neighbours updated later in the colour order); its restriction must equal R (b - A x_new) from the stand-alone operator
+    and restriction kernels, from zero and from a given x_old, on every stored level (odd / even sizes, chunk edges)."""
+    mv = make_case(kind, shape, npairs, seed)
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=coarse_precision,
+                              vcycle_precision=vcycle_precision)
+    rng = np.random.default_rng(seed)
+    # float32 vectors: the stand-alone residual also sees the rounding of x_new to float32 (D_i x_i = ... no longer holds to
+    # float64 accuracy), the update formula does not: agreement to float32 rounding x the size of the diagonal blocks
+    tol = 1e-11 if vcycle_precision == 0 else 5e-4
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        s.debug_setup(mv, p)
+        for lvl in range(1, s.num_levels - 1):
+            b = rng.standard_normal((npairs, 3) + s.level_shape(lvl))
+            for x_old in (None, rng.standard_normal(b.shape)):
+                x_new = s.debug_sweep(lvl, np.zeros_like(b) if x_old is None else x_old, b, from_zero=x_old is None)
+                want = s.debug_restrict(lvl, b - s.debug_apply(lvl, x_new))
+                got = s.debug_resrestrict_u(lvl, x_new, x_old)
+                scale = np.linalg.norm(s.debug_restrict(lvl, b))
+                assert np.linalg.norm(got - want) < tol * scale, (lvl, x_old is None, np.linalg.norm(got - want) / scale)
+
+
 def test_vcycle_fused_equals_per_colour(native):
     mv = make_case("texture", (130, 130), 2, 3)
     p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4)
