@@ -114,6 +114,7 @@ struct vof_ctx {
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
     bool fuse_prolong = true;   // level 0: coarse-grid correction interpolated inside the first post-sweep
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
+    bool sweep_st = true;       // stored levels, 32-bit stencils: k_sweep_st (VOF_SWEEP_ST=0: the generic k_sweep)
     bool fuse_resu = true;      // stored levels: coarse right-hand side from the last pre-smoothing sweep's update (k_resrestrict_u;
                                 // VOF_FUSE_RESU=0: stand-alone residual + restriction kernels)
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
@@ -497,6 +498,10 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
     } else {
         Prof p(c, VOF_K_GS, l, (coef_bytes(c, l) + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
+        if (geoB && c->sweep_st && !ecoarse && l > 0 && c->cfmt == 2) {   // packed bfloat16 stencils: the kernel with the decoupled coefficient stream
+            k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>((const uint32_t*)lv.C, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+            return;
+        }
         CDISPATCH(c, l, {
             SweepStored<CT> pol; pol.C = (const CW*)lv.C; pol.plane = CLay(lv.ni, lv.nj).plane;
             if (geoB) k_sweep<SweepStored<CT>, GeoB, VT><<<g, GeoB::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
@@ -1322,6 +1327,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_FUSE_RESTRICT")) c->fuse_restrict = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_RESU")) c->fuse_resu = e[0] != '0';
+    if (const char* e = getenv("VOF_SWEEP_ST")) c->sweep_st = e[0] != '0';
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';

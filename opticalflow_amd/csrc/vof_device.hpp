@@ -2089,6 +2089,240 @@ __global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, i
 }
 
 // ==========================================================================================
+// k_sweep_st: the fused 4-colour sweep of a STORED level (32-bit stencil formats, GeoB geometry, no coarse-grid correction)
+// with the coefficient stream decoupled from the step barrier.  Same schedule, ring and results as
+// k_sweep<SweepStored<CT>, GeoB, VT>; what changes is when the memory operations are issued and how they are waited for:
+//  * two coefficient sets in registers: the 45 words of the point of step s + 1 are requested at the START of step s (the
+//    generic kernel requests them at its end, i.e. just before the barrier after which they are needed - the "prefetch"
+//    hid a barrier, not a memory latency), after the row loads of the step, so that waiting for the rows never waits for
+//    the coefficients (vector-memory results return in order);
+//  * the steps in which every row touched exists run a body whose loads are all unconditional (clamped addresses): with
+//    loads inside branches the compiler cannot count the operations in flight and emits s_waitcnt vmcnt(0), which drains
+//    the whole stream at every wait.  These steps have their own loop (two steps per iteration, static register sets), entered
+//    after a full wait, so the counts on its back edge are exact;
+//  * the point update reads its neighbours row by row, so that two coefficient sets fit the register budget of 10 waves
+//    per CU.
+// ==========================================================================================
+template <typename CT, typename VT>
+__global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, int TI,
+                                                               int po, int nx, int ny, int nz, const VT* __restrict__ x_in,
+                                                               VT* __restrict__ x_out, const VT* __restrict__ b,
+                                                               const int* __restrict__ active) {
+    typedef GeoB G;
+    typedef typename CoefFmt<CT>::word_t word_t;
+    constexpr int W = G::W, OUT = G::OUT, THREADS = G::THREADS, PLANES = CoefFmt<CT>::PLANES;
+    extern __shared__ double sw_lds[];
+    VT* xs = reinterpret_cast<VT*>(sw_lds);                                                     // [SW_RING][3][W]
+    const unsigned nblocks = (unsigned)nx * ny * nz;
+    unsigned lb = blockIdx.x;
+    if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
+    const int bx = lb % nx, by = (lb / nx) % ny;
+    const int pair = lb / (nx * ny);
+    if (active && !active[pair]) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p0 = by * TI - po;
+    const int qs = bx * OUT - SW_HALO;
+    const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
+    const VT* xin = x_in ? x_in + off : nullptr;
+    VT* xout = x_out + off;
+    const VT* bp = b + off;
+    const CLay L(ni, nj);
+    const word_t* Cp = C + (size_t)pair * PLANES * L.plane;
+
+    // ---- stage of this lane.  Waves 0-3: colour = wave; wave 4 recomputes the six halo points (see k_sweep).
+    int stage = wave, lc;
+    bool lane_on = true;
+    lc = SW_HALO + 2 * lane + ((wave & 1) ^ po);
+    if (wave == 4) {
+        const int hs[6] = {0, 0, 0, 1, 1, 2};
+        const int hl[6] = {2, SW_HALO + OUT, SW_HALO + OUT + 2, 3, SW_HALO + OUT + 1, SW_HALO + OUT};
+        lane_on = lane < 6;
+        stage = hs[lane_on ? lane : 0];
+        lc = hl[lane_on ? lane : 0];
+        if (po) lc = W - 1 - lc;
+    }
+    const int q = qs + lc;
+    const bool col_ok = lane_on && (q >= 0) && (q < nj);
+    const int qc = col_ok ? q : 0, lcc = col_ok ? lc : 2;
+    const int cC = sw_cs<G>(lcc), uL = sw_cs<G>(lcc - 1), uR = sw_cs<G>(lcc + 1);
+    const unsigned ccq = (unsigned)((size_t)(qc & 1) * L.sub + (size_t)(qc >> 1));   // column part of the stencil index
+    const unsigned bcol = (unsigned)qc;
+    // ---- cooperative load-in / write-out of 2 rows x 3 fields x W columns per step: thread <-> (row, column) of the two
+    // rows (2 x 136 of the 320 threads), the three fields are the unrolled index
+    const int m_row = tid >= W ? 1 : 0, m_col = tid - m_row * W;
+    const bool m_on = tid < 2 * W;
+    const int m_q = qs + m_col;
+    const bool m_ld = m_on && m_q >= 0 && m_q < nj;
+    const bool m_st = m_ld && m_col >= SW_HALO && m_col < SW_HALO + OUT;
+    const unsigned m_g = m_ld ? (unsigned)m_q : 0u;
+    const int m_lds = sw_cs<G>(m_on ? m_col : 0);
+    const int sro = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
+    const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
+    const bool uni = wave < 4;                           // colour waves: the stage's row is wave-uniform
+    const int sro_u = __builtin_amdgcn_readfirstlane(sro);
+
+    // coefficients of the stage's point, this step's / the next step's: two sets of the off-diagonal words (planes 0 .. ND - 1),
+    // one set of the diagonal block (planes ND ..), which is requested when the update that used the previous one is done
+    constexpr int ND = std::is_same<CT, CoefB16>::value ? 36 : 36;   // (packed bfloat16: 36 words + 9 floats)
+    static_assert(std::is_same<CT, CoefB16>::value, "k_sweep_st is written for the packed bfloat16 stencils");
+    word_t cw[2][ND], dg[PLANES - ND];
+    VT bq[3];                                            // b of the stage's point: requested with the diagonal block
+#pragma unroll
+    for (int k = 0; k < ND; ++k) cw[0][k] = cw[1][k] = 0;
+#pragma unroll
+    for (int k = 0; k < PLANES - ND; ++k) dg[k] = 0;
+    bq[0] = bq[1] = bq[2] = (VT)0;
+    auto offd = [](const word_t* w, int j) {   // off-diagonal coefficient j (0..71) of a set
+        const uint32_t v = w[j >> 1];
+        return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+    };
+
+    // base pointer (wave-uniform part) and lane index of the stencil words of the stage's point in row pn
+    auto point_base = [&](const int pn, const word_t*& base, unsigned& idx, const bool fast) {
+        if (fast && uni) {
+            const int pnu = __builtin_amdgcn_readfirstlane(pn);
+            base = Cp + (size_t)((pnu & 1) << 1) * L.sub + (size_t)(pnu >> 1) * L.hj;
+            idx = ccq;
+        } else {
+            base = Cp;
+            idx = (unsigned)((size_t)((pn & 1) << 1) * L.sub + (size_t)(pn >> 1) * L.hj) + ccq;
+        }
+    };
+    // off-diagonal stencil words of the stage's point of the step with e = eN -> set J
+    auto fetch_point = [&](auto fast_tag, auto jtag, const int eN) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int J = decltype(jtag)::value;
+        const int rrn = eN + sro, pn = p0 + rrn;
+        if (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)) {
+            const word_t* base; unsigned idx;
+            point_base(pn, base, idx, FAST);
+#pragma unroll
+            for (int k = 0; k < ND; ++k) cw[J][k] = (base + (size_t)k * L.plane)[idx];
+        }
+    };
+    // diagonal block and b of the stage's point of the step with e = eN
+    auto fetch_diag = [&](auto fast_tag, const int eN) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int rrn = eN + sro, pn = p0 + rrn;
+        if (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)) {
+            const word_t* base; unsigned idx;
+            point_base(pn, base, idx, FAST);
+#pragma unroll
+            for (int k = 0; k < PLANES - ND; ++k) dg[k] = (base + (size_t)(ND + k) * L.plane)[idx];
+            const VT* brow = bp + (size_t)pn * nj + bcol;
+            bq[0] = brow[0]; bq[1] = brow[npts]; bq[2] = brow[2 * npts];
+        }
+    };
+
+    int slotA = sw_slot(-2);   // ring slot of relative row e + 2, advanced by 2 per step
+    // JC: set of this step's point, 1 - JC: set requested for the next step
+    auto step = [&](auto fast_tag, auto jtag, const int e) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int JC = decltype(jtag)::value;
+        const int slotB = slotA + 1;
+        const bool do_load = FAST ? true : (e + 2 <= TI + 1);
+        // (1) write-out of the rows that became final: relative rows e - 10, e - 9
+        {
+            const int rrA = e - 10, rrB = e - 9, pA = p0 + rrA, pB = p0 + rrB;
+            const bool okA = FAST ? true : (rrA >= 0 && rrA < TI && pA >= 0 && pA < ni);
+            const bool okB = FAST ? true : (rrB >= 0 && rrB < TI && pB >= 0 && pB < ni);
+            const bool rowok = m_row ? okB : okA;
+            if (m_st && rowok) {
+                const int slot = m_row ? slotB : slotA;
+                VT* orow = xout + (size_t)(m_row ? pB : pA) * nj + m_g;
+                const VT* lrow = xs + slot * 3 * W + m_lds;
+                orow[0] = lrow[0]; orow[npts] = lrow[W]; orow[2 * npts] = lrow[2 * W];
+            }
+        }
+        // (2) rows e + 2, e + 3 -> registers (moved into the ring in (5)), then the next step's point
+        VT lx[3] = {(VT)0, (VT)0, (VT)0};
+        if (xin) {
+            const int pR = p0 + e + 2 + m_row;
+            if (FAST) {
+                const VT* irow = xin + (size_t)pR * nj + m_g;
+                // (columns outside the grid take the value of a clamped address instead of 0: they only ever meet the zero
+                // coefficients of out-of-grid neighbours, and a select here would be a wait for the load just issued)
+                lx[0] = irow[0]; lx[1] = irow[npts]; lx[2] = irow[2 * npts];
+            } else if (m_ld && do_load && pR >= 0 && pR < ni) {
+                const VT* irow = xin + (size_t)pR * nj + m_g;
+                lx[0] = irow[0]; lx[1] = irow[npts]; lx[2] = irow[2 * npts];
+            }
+        }
+        fetch_point(fast_tag, std::integral_constant<int, 1 - JC>{}, e + 2);
+        // (4) the stage of this lane: block Gauss-Seidel update of its point, neighbours read row by row
+        {
+            const int rr = e + sro, p = p0 + rr;
+            if (col_ok && (FAST || (rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni))) {
+                const int sU = sw_wrap(slotA + SW_RING + sro - 3), sC = sw_wrap(slotA + SW_RING + sro - 2),
+                          sD = sw_wrap(slotA + SW_RING + sro - 1);
+                const int rowo[3] = {sU * 3 * W, sC * 3 * W, sD * 3 * W};
+                const int colo[3] = {uL, cC, uR};
+                const word_t* c_ = cw[JC];
+                double y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const VT* row = xs + rowo[a];
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) {
+                        if (a == 1 && bb == 1) continue;
+                        double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
+                        const int d = a * 3 + bb, t0 = (d < 4 ? d : d - 1) * 9;
+                        y0 += offd(c_, t0 + 0) * xu + offd(c_, t0 + 1) * xw + offd(c_, t0 + 2) * xg;
+                        y1 += offd(c_, t0 + 3) * xu + offd(c_, t0 + 4) * xw + offd(c_, t0 + 5) * xg;
+                        y2 += offd(c_, t0 + 6) * xu + offd(c_, t0 + 7) * xw + offd(c_, t0 + 8) * xg;
+                    }
+#ifndef SWST_NO_ROW_FENCE
+                    asm volatile("" ::: "memory");   // keep the LDS reads of the next row behind this row's arithmetic
+#endif
+                }
+                double Dm[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) Dm[t] = (double)__uint_as_float(dg[t]);
+                double u, w, gm;
+                solve3(Dm, (double)bq[0] - y0, (double)bq[1] - y1, (double)bq[2] - y2, u, w, gm);
+                VT* row = xs + rowo[1] + cC;
+                row[0] = (VT)u; row[W] = (VT)w; row[2 * W] = (VT)gm;
+            }
+        }
+        fetch_diag(fast_tag, e + 2);   // the diagonal block of the next step's point (the registers are free now)
+        // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
+        if (do_load && m_on) {
+            VT* lrow = xs + (m_row ? slotB : slotA) * 3 * W + m_lds;
+            lrow[0] = lx[0]; lrow[W] = lx[1]; lrow[2 * W] = lx[2];
+        }
+        slotA = sw_wrap(slotA + 2);
+        __syncthreads();
+    };
+
+    // Steps s = -2 .. TI / 2 + 4 (e = 2 s); step n = s + 2 uses set n & 1.  A step is FAST when every row it touches - written
+    // out (e - 10, e - 9), loaded (e + 2, e + 3), updated (e, e - 2, e - 5, e - 7, all inside their colour's row range) - and
+    // every row the NEXT step updates exists.
+    const int s_end = TI / 2 + 4;
+    // lower bounds: write-out row e - 10 >= 0 and inside the grid (the updated rows e - 7 .. e follow); upper bounds: loaded
+    // row e + 3 <= TI + 1 and inside the grid, the next step's updated row e + 2 <= TI
+    const int e_lo = max(10, 10 - p0);
+    const int e_hi = min(TI - 2, ni - 4 - p0);
+    auto pair_fast = [&](const int s) { return 2 * s >= e_lo && 2 * (s + 1) <= e_hi; };
+    int s = -2;
+    for (int part = 0; part < 2; ++part) {
+        while (s <= s_end && (part == 1 || !pair_fast(s))) {
+            step(std::false_type{}, std::integral_constant<int, 0>{}, 2 * s);
+            if (s + 1 <= s_end) step(std::false_type{}, std::integral_constant<int, 1>{}, 2 * (s + 1));
+            s += 2;
+        }
+        if (part == 0 && s <= s_end) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing requested by the predicated steps is still in flight
+            while (pair_fast(s)) {
+                step(std::true_type{}, std::integral_constant<int, 0>{}, 2 * s);
+                step(std::true_type{}, std::integral_constant<int, 1>{}, 2 * (s + 1));
+                s += 2;
+            }
+        }
+    }
+}
+
+// ==========================================================================================
 // k_sweep0: the fused 4-colour sweep of level 0 (matrix-free), the north-star kernel.  Same schedule, strip geometry
 // (120 owned + 2 x 4 halo columns, 4 colour waves, 12-row ring, bands of TI rows) and results as
 // k_sweep<SweepFine, GeoA> above - bit for bit - but the row loop is rebuilt around its instruction budget (the PMC
