@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--pairs-in-flight", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="bfloat16", choices=["float64", "float32", "bfloat16"])
-    ap.add_argument("--vcycle-precision", default="float64", choices=["float64", "float32", "auto"])
+    ap.add_argument("--vcycle-precision", default="coarse_float32", choices=["float64", "float32", "auto", "coarse_float32"])
     ap.add_argument("--nu-pre", type=int, default=2)
     ap.add_argument("--nu-post", type=int, default=2)
     ap.add_argument("--nu-pre-coarse", type=int, default=1)
@@ -213,7 +213,7 @@ def main():
 
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
                                     coarse_precision={"float64": 0, "float32": 1, "bfloat16": 2}[args.coarse_precision],
-                                    vcycle_precision={"float64": 0, "float32": 1, "auto": 2}[args.vcycle_precision],
+                                    vcycle_precision={"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3}[args.vcycle_precision],
                                     nu_pre=args.nu_pre, nu_post=args.nu_post, nu_pre_coarse=args.nu_pre_coarse,
                                     nu_post_coarse=args.nu_post_coarse)
     if args.w_cycle_level is not None:
@@ -373,19 +373,20 @@ def main():
                       w_cycle_level=int(params.w_cycle_level), w_cycle_visits=int(params.w_cycle_visits),
                       warm_start_stride=int(params.warm_start_stride))
         cold = dict(common, warm_start_stride=0)
-        cp = int(params.coarse_precision)
+        cp, vp = int(params.coarse_precision), int(params.vcycle_precision)
         out["variants"] = {
-            "constant_initial_fields_for_every_pair": timed(_native.default_params(vcycle_precision=0, coarse_precision=cp, **cold)),
+            "constant_initial_fields_for_every_pair": timed(_native.default_params(vcycle_precision=vp, coarse_precision=cp, **cold)),
             "all_float64_storage": timed(_native.default_params(vcycle_precision=0, coarse_precision=0, **common)),
-            "float32_stencils": timed(_native.default_params(vcycle_precision=0, coarse_precision=1, **common)),
-            "default_stencils_auto_float32_vectors": timed(_native.default_params(vcycle_precision=2, coarse_precision=cp, **common)),
+            "float32_stencils": timed(_native.default_params(vcycle_precision=vp, coarse_precision=1, **common)),
+            "float64_vcycle_vectors_on_every_level": timed(_native.default_params(vcycle_precision=0, coarse_precision=cp, **common)),
+            "float32_vcycle_vectors_on_every_level": timed(_native.default_params(vcycle_precision=2, coarse_precision=cp, **common)),
         }
         if not args.wobble:
             # a less warm-start-friendly sibling of the headline input: the same texture with a time-varying flow
             # (frame-to-frame step (0.3, 0.6) x (1 +- 0.3)), default settings
             wob = [texture_stack_torch(n, T, seed, dev, first_frame=0, solver=solver, wobble=0.3)]
             out["variants"]["time_varying_flow_wobble_0.3"] = timed(params, wob)
-            out["variants"]["time_varying_flow_wobble_0.3_cold"] = timed(_native.default_params(vcycle_precision=0, coarse_precision=cp, **cold), wob)
+            out["variants"]["time_varying_flow_wobble_0.3_cold"] = timed(_native.default_params(vcycle_precision=vp, coarse_precision=cp, **cold), wob)
             del wob
     if world == 1 and not use_dist and not args.no_end_to_end:
         # end-to-end rate of the drop-in call, pageable numpy arrays in and out (the reference's

@@ -48,8 +48,9 @@ typedef struct vof_params {
     int32_t coarse_precision;  /* storage of the Galerkin stencils (preconditioner only): 2 (default) bfloat16 off-diagonal blocks +
                                   float32 diagonal block that absorbs their rounding errors (block row sums kept; same iteration
                                   counts as float32, 180 instead of 324 bytes per coarse point); 1: float32; 0: float64 */
-    int32_t vcycle_precision;  /* V-cycle vectors: 0 (default) float64; 1 float32 storage; 2 auto = float32 for the first 8
-                                  iterations, float64 afterwards (arithmetic, Krylov vectors and stopping rule always FP64) */
+    int32_t vcycle_precision;  /* storage of the V-cycle vectors: 0 float64; 1 float32; 2 auto = float32 for the first 8
+                                  iterations, float64 afterwards; 3 (default) = float64 on level 0, float32 on the levels below
+                                  for the first 8 iterations (arithmetic, Krylov vectors and stopping rule always FP64) */
     int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
     int32_t nu_post_coarse;
     int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 w_cycle_visits times per cycle (a one-level W-cycle); -1: V-cycle */

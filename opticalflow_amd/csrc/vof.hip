@@ -65,6 +65,8 @@ struct vof_ctx {
     double* kz = nullptr;
     double* b32 = nullptr;  // V-typed copy of the V-cycle right-hand side (p or s) when vfloat
     bool vfloat = false;    // V-cycle vectors stored as float32 (arithmetic stays FP64)
+    bool vcoarse32 = false; // vcycle_precision 3: float64 vectors on level 0, float32 on the levels below (the two meet in the fused
+                            // residual + restriction kernel and in the post-smoothing pass that interpolates the correction)
     const PairParam* pp = nullptr;   // per-pair (alpha, beta, frame) overrides of the current batch ("virtual pairs") or nullptr
     PairParam* pp_buf = nullptr;     // device storage for them (B entries, lazy)
     // warm start (two-phase solve of a stack): interior solutions of the phase-1 pairs, and per pair of the current
@@ -370,13 +372,13 @@ void restrict_level_t(vof_ctx* c, int l, const VT* fine, VT* coarse, int np, con
 }
 
 // level 0, matrix-free: coarse right-hand side b_1 = R (b - A x) in one pass (no fine residual in HBM)
-template <typename VT>
-void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, VT* bc, int np, const int* active) {
+template <typename VT, typename CVT = VT>
+void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, CVT* bc, int np, const int* active) {
     Level &f = c->L[0], &k = c->L[1];
     int TI = pick_band_height(f.ni, (k.nj + RR_CO - 1) / RR_CO, c->cur_units);
     dim3 g((k.nj + RR_CO - 1) / RR_CO, (k.ni + TI / 2 - 1) / (TI / 2), np);
-    Prof p(c, VOF_K_APPLY0, 0, (8.0 + 6.0 * sizeof(VT)) * f.npts + 3.0 * sizeof(VT) * k.npts);
-    k_stream_resrestrict0<VT, VT, VT><<<g, AP_THREADS, 0, c->stream>>>(
+    Prof p(c, VOF_K_APPLY0, 0, (8.0 + 6.0 * sizeof(VT)) * f.npts + 3.0 * sizeof(CVT) * k.npts);
+    k_stream_resrestrict0<VT, VT, CVT><<<g, AP_THREADS, 0, c->stream>>>(
         c->frames, frame_stride(c), c->Nj, f.ni, f.nj, TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
         c->prm.reference_quirks, x, b, bc, k.ni, k.nj, active, c->pp);
 }
@@ -424,7 +426,8 @@ inline bool sweep0m_usable(const vof_ctx* c) {
 // nsweeps = 2 (level 0, k_sweep0m only): two consecutive sweeps in one pass.
 template <typename VT>
 void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
-                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1, bool with_trail = false) {
+                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1, bool with_trail = false, bool ec32 = false) {
+    // ec32: `ecoarse` really points at float32 data (float64 level 0 above float32 coarse levels; k_sweep0m only)
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
     int rows = lv.ni + po;
@@ -440,7 +443,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             dim3 g((unsigned)nx * ny * np, 1, 1);
             int nci = 0, ncj = 0;
             double ebytes = 0.0;
-            if (ecoarse) { nci = c->L[1].ni; ncj = c->L[1].nj; ebytes = 24.0 * c->L[1].npts; }
+            if (ecoarse) { nci = c->L[1].ni; ncj = c->L[1].nj; ebytes = (ec32 ? 12.0 : 24.0) * c->L[1].npts; }
             // bytes the pass moves: I + b(3) + x(3) in, x(3) out (+ coarse e), whatever the number of fused sweeps; algorithmic
             // bytes (80 per sweep performed): the second sweep of a double pass counts as a full sweep
             double moved = (8.0 + (x_in ? 9.0 : 6.0) * 8.0) * lv.npts + ebytes;
@@ -459,7 +462,9 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             const size_t lds = (size_t)(6 * NSW + 2 + (trail ? 4 : 0)) * s0_row_bytes(8) + (ecoarse ? (size_t)9 * (S0_W / 2 + 2) * 8 : 0);
 #define VOF_LAUNCH_S0M(NS_)                                                                                                        \
             do {                                                                                                                    \
-                if (trail && ecoarse) k_sweep0m<NS_, true, false, 1><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                if (trail && ecoarse && ec32) k_sweep0m<NS_, true, false, 1, float><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr); \
+                else if (ecoarse && ec32) k_sweep0m<NS_, true, false, 0, float><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr); \
+                else if (trail && ecoarse) k_sweep0m<NS_, true, false, 1><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (trail) k_sweep0m<NS_, false, false, 1><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (ecoarse) k_sweep0m<NS_, true, false, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (!x_in) k_sweep0m<NS_, false, true, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
@@ -513,7 +518,8 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
 // nu sweeps (from a zero guess if from_zero, else from x); the result is guaranteed to end in `x`.
 template <typename VT>
 VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
-                   const int* active, const VT* ecoarse = nullptr, bool allow_swap = false, bool final_smooth = false) {
+                   const int* active, const VT* ecoarse = nullptr, bool allow_swap = false, bool final_smooth = false,
+                   bool ec32 = false) {
     // Returns the buffer that holds the result: `x`, or `tmp` when allow_swap is set and the last out-of-place sweep
     // ended there (saves a device-to-device copy on the coarse levels).
     // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
@@ -548,7 +554,7 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
         // the cycle's very last pass also delivers the Krylov product of its result, if one was requested
         const bool trail = final_smooth && s == npass - 1 && c->trail_set && c->trail_enabled && l == 0 &&
                            std::is_same<VT, double>::value && sweep0m_usable(c) && src != nullptr;
-        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns, trail);
+        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns, trail, ec32);
         left -= ns;
         src = dst;
         dst = (dst == x) ? tmp : x;
@@ -607,6 +613,13 @@ void tail_cycle_t(vof_ctx* c, VT* x, const VT* b, int np, const int* active, boo
     CDISPATCH(c, l0, (k_tail_cycle<CT, VT><<<np, TAIL_THREADS, c->tail_lds, c->stream>>>(A, b, x, from_zero ? 1 : 0, active)));
 }
 
+// vcycle_precision 3 applies when level 0 runs the kernels in which the two storage types meet: k_stream_resrestrict0 (float64
+// in, float32 out) and k_sweep0m with the interpolated correction (float32 in); anything else keeps float64 everywhere
+inline bool coarse32_ok(const vof_ctx* c, int nu_post) {
+    return c->vcoarse32 && !c->vfloat && c->L.size() > 1 && c->L[0].C == nullptr && sweep0m_usable(c) && c->fuse_prolong &&
+           c->fuse_restrict && c->stream_apply && nu_post > 0;
+}
+
 // One multigrid cycle on level l for A_l x = b, starting from a zero guess (from_zero) or from the contents of x.
 // (x, tmp) are the level's ping-pong buffers.  Returns the buffer holding the result: `x`, or - on the levels >= 1,
 // where the caller only reads it - `tmp`.  With prm.w_cycle_level == l the next coarser level is visited twice
@@ -629,6 +642,25 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
         if (xr != x) std::swap(x, tmp);
     } else {
         smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active);
+    }
+    if constexpr (std::is_same<VT, double>::value) {
+        if (l == 0 && coarse32_ok(c, nu2)) {
+            // float64 vectors on level 0, float32 below: the fused residual + restriction writes the coarse right-hand side as
+            // float32, the levels below run in float32, and the post-smoothing pass interpolates the float32 correction
+            resrestrict_fine_t<double, float>(c, x, b, (float*)nx.b, np, active);
+            float* fx = (float*)nx.x;
+            float* ft = (float*)nx.x2;
+            float* fe = vcycle_t<float>(c, 1, fx, ft, (const float*)nx.b, np, active, true);
+            if (c->prm.w_cycle_level == 0 && 1 < last) {
+                const int visits = c->prm.w_cycle_visits > 0 ? c->prm.w_cycle_visits : 2;
+                for (int v = 1; v < visits; ++v) {
+                    float* other = (fe == fx) ? ft : fx;
+                    fe = vcycle_t<float>(c, 1, fe, other, (const float*)nx.b, np, active, false);
+                }
+            }
+            return smooth_level_t<double>(c, 0, x, tmp, b, nu2, false, true, np, active, (const double*)fe, /*allow_swap=*/true,
+                                          /*final_smooth=*/true, /*ec32=*/true);
+        }
     }
     if (resu) {
         const VT* x_old = (from_zero && nu1 == 1) ? nullptr : tmp;
@@ -804,6 +836,7 @@ int gmres_phase(vof_ctx* c, int np, int* handed_over) {
     c->gmres_pairs += nact;
     const int m = std::min(c->gm_m, P.gmres_restart > 0 ? P.gmres_restart : 100);
     c->vfloat = false;   // float64 cycle vectors: the basis vectors are the cycle's right-hand sides
+    c->vcoarse32 = false;
     double* V = c->gm_V;
     double* w = c->kt;
     const dim3 rg = rgrid(c, np);
@@ -1027,7 +1060,8 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     const vof_params& P = c->prm;
     // storage type of the cycle vectors for this batch (an earlier batch may have switched to float64: "auto"
     // precision after 8 iterations, GMRES fallback)
-    c->vfloat = P.vcycle_precision >= 1 && c->fused && c->L.size() > 1 && !c->direct_on;
+    c->vfloat = (P.vcycle_precision == 1 || P.vcycle_precision == 2) && c->fused && c->L.size() > 1 && !c->direct_on;
+    c->vcoarse32 = P.vcycle_precision == 3 && !c->direct_on;
     if (c->direct_on) {   // direct preconditioner: block-tridiagonal LU instead of the Galerkin hierarchy
         if (np > c->dir_cap) { c->err = "batch larger than the direct preconditioner's buffers"; return -1; }
         c->frames = frames_dev;
@@ -1080,7 +1114,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         if (nact == 0) break;
         // vcycle_precision 2 ("auto"): float32 V-cycle vectors for the first iterations, float64 for stragglers
         // (in the slowly converging regimes float32 storage costs iterations)
-        if (P.vcycle_precision == 2 && it_total == AUTO_F64_AFTER) c->vfloat = false;
+        if (it_total == AUTO_F64_AFTER) { if (P.vcycle_precision == 2) c->vfloat = false; c->vcoarse32 = false; }
         c->cur_units = nact;
         const int* act = c->active;
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
@@ -1194,7 +1228,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->w_cycle_visits < 0 || p->w_cycle_visits > 8) { c->err = "w_cycle_visits must be in [0, 8]"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision < 0 || p->coarse_precision > 2) { c->err = "coarse_precision must be 0, 1 or 2"; return -1; }
-    if (p->vcycle_precision < 0 || p->vcycle_precision > 2) { c->err = "vcycle_precision must be 0, 1 or 2"; return -1; }
+    if (p->vcycle_precision < 0 || p->vcycle_precision > 3) { c->err = "vcycle_precision must be 0, 1, 2 or 3"; return -1; }
     if (p->krylov_method < 0 || p->krylov_method > 2) { c->err = "krylov_method must be 0, 1 or 2"; return -1; }
     if (p->gmres_restart < 0 || p->gmres_restart > GM_MAXM) { c->err = "gmres_restart must be in [0, 128]"; return -1; }
     if (p->fallback_after < 0) { c->err = "fallback_after must be >= 0"; return -1; }
@@ -1202,7 +1236,8 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->preconditioner < 0 || p->preconditioner > 2) { c->err = "preconditioner must be 0, 1 or 2"; return -1; }
     c->prm = *p;
     // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
-    c->vfloat = p->vcycle_precision >= 1 && c->fused && c->L.size() > 1;
+    c->vfloat = (p->vcycle_precision == 1 || p->vcycle_precision == 2) && c->fused && c->L.size() > 1;
+    c->vcoarse32 = false;   // set per batch (solve_batch); the debug entry points run every level in one storage type
     return 0;
 }
 
@@ -1235,7 +1270,7 @@ int vof_default_params(vof_params* p, size_t struct_size) {
     p->reference_quirks = 1;
     p->coarse_precision = 2;       // Galerkin stencils (preconditioner only): bfloat16 off-diagonal blocks, float32 diagonal
                                    // block that keeps the block row sums - same iteration counts as float32 in every regime
-    p->vcycle_precision = 0;       // float64 V-cycle vectors (1: float32 storage, FP64 arithmetic)
+    p->vcycle_precision = 3;       // float64 V-cycle vectors on level 0, float32 below (0: float64 everywhere, 1: float32 everywhere)
     p->krylov_method = 2;          // BiCGStab (the reference's 'bcgs'); stragglers are finished by restarted GMRES
     p->gmres_restart = 100;        // capped by the free device memory: (restart + 1) vectors per pair in flight
     p->warm_start_stride = 3;      // vof_solve_stack_dev: every 3rd pair first, the others start from their solved neighbour

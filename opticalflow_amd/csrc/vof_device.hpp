@@ -2672,11 +2672,12 @@ struct S0Trail {           // trailing operator stage (TRAIL = 1): v = A x_out, 
     double* partials;     // [pair][3][nblk], nblk = nx * ny blocks per pair
 };
 
-template <int NS, bool EC, bool FROM_ZERO, int TRAIL = 0>
+// ET: storage type of the coarse-grid correction (float when the levels below 0 keep their vectors in float32)
+template <int NS, bool EC, bool FROM_ZERO, int TRAIL = 0, typename ET = double>
 __global__ __launch_bounds__(128 * NS) void k_sweep0m(
     Fine0 pol, int ni, int nj, int TI, int po, int nx, int ny, int nz, const double* __restrict__ x_in,
     double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
-    const double* __restrict__ ecoarse, int nci, int ncj, S0Trail tr) {
+    const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr) {
     typedef S0M<NS, TRAIL> G;
     constexpr int W = S0_W, IW = S0_IW, NW = G::NW, R = G::R, RSB = G::RSB, RINGB = R * RSB, CRW = G::CRW;
     constexpr int EXT = G::EXT, WOFF = G::WOFF;
@@ -2699,7 +2700,7 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(
     double* xout = x_out + off;
     const double* bp = b + off;
     const size_t ncpts = (size_t)nci * ncj;
-    const double* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
+    const ET* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
     double alpha = pol.alpha, beta = pol.beta;
     int fidx = pair;
     if (pol.pp) { alpha = pol.pp[pair].alpha; beta = pol.pp[pair].beta; fidx = pol.pp[pair].frame; }
@@ -2825,14 +2826,23 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(
                 }
             }
         }
-        double crv0 = 0.0, crv1 = 0.0, crw0 = 0.0, crw1 = 0.0, cru0 = 0.0, cru1 = 0.0;
-        const int knew = ((p0 + e + 4) >> 1) + 1;          // coarse row needed by the NEXT step
+        // coarse row needed by the NEXT step: field wave + k NW of it is fetched (and later stored) by this wave - the fields are
+        // dealt to the waves so that no wave carries all of this extra duty (the waves of a step wait for the slowest one);
+        // kept as loaded: a conversion here would be a wait for the load
+        constexpr int NEC = (3 + NW - 1) / NW;
+        ET crv[NEC][2];
+        const int knew = ((p0 + e + 4) >> 1) + 1;
         if (EC) {
-            if (wave == 0 && knew >= 0 && knew < nci) {
-                const int c0 = cqs + lane, c1 = cqs + 64 + lane;
-                const double* er = ec + (size_t)knew * ncj;
-                if (c0 >= 0 && c0 < ncj) { crv0 = er[c0]; crw0 = er[ncpts + c0]; cru0 = er[2 * ncpts + c0]; }
-                if (lane < 2 && c1 >= 0 && c1 < ncj) { crv1 = er[c1]; crw1 = er[ncpts + c1]; cru1 = er[2 * ncpts + c1]; }
+#pragma unroll
+            for (int k = 0; k < NEC; ++k) {
+                crv[k][0] = crv[k][1] = 0;
+                const int fe = wave + k * NW;
+                if (fe < 3 && knew >= 0 && knew < nci) {
+                    const int c0 = cqs + lane, c1 = cqs + 64 + lane;
+                    const ET* er = ec + (size_t)fe * ncpts + (size_t)knew * ncj;
+                    if (c0 >= 0 && c0 < ncj) crv[k][0] = er[c0];
+                    if (lane < 2 && c1 >= 0 && c1 < ncj) crv[k][1] = er[c1];
+                }
             }
         }
         // ---- (3) this step's b (prefetched during the previous step) and the prefetch for the next step
@@ -3024,10 +3034,14 @@ __global__ __launch_bounds__(128 * NS) void k_sweep0m(
                 }
             }
             if (EC) {
-                if (wave == 0) {
-                    double* cs = cr + cr_slot(knew) * 3 * CRW;
-                    cs[lane] = crv0; cs[CRW + lane] = crw0; cs[2 * CRW + lane] = cru0;
-                    if (lane < 2) { cs[64 + lane] = crv1; cs[CRW + 64 + lane] = crw1; cs[2 * CRW + 64 + lane] = cru1; }
+#pragma unroll
+                for (int k = 0; k < NEC; ++k) {
+                    const int fe = wave + k * NW;
+                    if (fe < 3) {
+                        double* cs = cr + (cr_slot(knew) * 3 + fe) * CRW;
+                        cs[lane] = (double)crv[k][0];
+                        if (lane < 2) cs[64 + lane] = (double)crv[k][1];
+                    }
                 }
             }
         }

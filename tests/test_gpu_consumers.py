@@ -235,9 +235,11 @@ def test_warm_started_stack_solve_equals_cold_solve():
             assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
         assert st["iterations"].sum() < cold_st["iterations"].sum()
         np.testing.assert_allclose(st["L1_functional"], cold_st["L1_functional"], rtol=1e-5)
-    # the pairs solved first (every 3rd) do not see the warm start: same iterations, same fields up to the summation
-    # order of the reductions (the band height of the streaming kernels follows the batch size)
-    np.testing.assert_allclose(outs["warm"][0][0][::3], cold_fields[0][::3], rtol=1e-9, atol=1e-12)
+    # the pairs solved first (every 3rd) do not see the warm start: same iterations, same fields up to what the summation
+    # order of the reductions can do (the band height of the streaming kernels follows the batch size: the Krylov scalars
+    # differ in their last bits, which the float32 storage of the coarse-level cycle vectors turns into differences of the
+    # preconditioner's output at the 1e-7 level - both runs then stop at rtol 1e-9, i.e. agree to about that)
+    np.testing.assert_allclose(outs["warm"][0][0][::3], cold_fields[0][::3], rtol=2e-8, atol=1e-11)
     np.testing.assert_array_equal(outs["warm"][1]["iterations"][::3], cold_st["iterations"][::3])
 
 

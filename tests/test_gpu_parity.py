@@ -400,7 +400,7 @@ def test_seeded_random_configurations_against_oracle(of, case):
               initial_v_x=float(rng.uniform(-0.5, 0.5)), initial_v_y=float(rng.uniform(-0.5, 0.5)),
               initial_remodelling=float(rng.uniform(-0.1, 0.1)), reference_quirks=bool(case % 5 != 0))
     opts = dict(krylov_method=["auto", "bicgstab", "gmres"][case % 3], coarse_precision=["bfloat16", "float32", "float64", "bfloat16"][case % 4],
-                vcycle_precision=["float64", "float32", "auto"][(case // 2) % 3], w_cycle_level=[None, -1, 0, (1, 2)][case % 4],
+                vcycle_precision=["float64", "float32", "auto", "coarse_float32"][(case // 2) % 4], w_cycle_level=[None, -1, 0, (1, 2)][case % 4],
                 multigrid_sweeps=[None, (1, 1), (2, 1, 2, 2), (3, 3)][(case // 3) % 4], max_pairs_in_flight=[None, 1, 2][case % 3])
     ref = orc.variational_optical_flow(movie, **kw)
     res = of.variational_optical_flow(movie, rtol=1e-10, return_stats=True, **kw, **opts)
@@ -432,7 +432,7 @@ def test_seeded_random_medium_sizes_by_independent_residual(of, case):
     alpha, beta = float(10 ** rng.uniform(-0.3, 1.5)), float(10 ** rng.uniform(1.0, 4.0))
     quirks = bool(case % 4 != 0)
     opts = dict(krylov_method=["auto", "gmres"][case % 2], coarse_precision=["bfloat16", "float32", "float64"][(case // 2) % 3],
-                vcycle_precision=["float64", "float32", "auto"][case % 3], w_cycle_level=[None, -1, (1, 2), 2][case % 4],
+                vcycle_precision=["float64", "float32", "auto", "coarse_float32"][case % 4], w_cycle_level=[None, -1, (1, 2), 2][case % 4],
                 max_pairs_in_flight=[None, 2][case % 2])
     res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, reference_quirks=quirks, rtol=1e-8,
                                       return_stats=True, **opts)
