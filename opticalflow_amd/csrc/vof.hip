@@ -65,6 +65,7 @@ struct vof_ctx {
     double* kz = nullptr;
     double* b32 = nullptr;  // V-typed copy of the V-cycle right-hand side (p or s) when vfloat
     bool vfloat = false;    // V-cycle vectors stored as float32 (arithmetic stays FP64)
+    bool emit64 = false;    // vcycle_precision 3: the level-1 visit in progress hands its result up as float64 (see vcycle_t)
     bool vcoarse32 = false; // vcycle_precision 3: float64 vectors on level 0, float32 on the levels below (the two meet in the fused
                             // residual + restriction kernel and in the post-smoothing pass that interpolates the correction)
     const PairParam* pp = nullptr;   // per-pair (alpha, beta, frame) overrides of the current batch ("virtual pairs") or nullptr
@@ -426,7 +427,9 @@ inline bool sweep0m_usable(const vof_ctx* c) {
 // nsweeps = 2 (level 0, k_sweep0m only): two consecutive sweeps in one pass.
 template <typename VT>
 void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
-                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1, bool with_trail = false, bool ec32 = false) {
+                   const int* active, const VT* ecoarse = nullptr, int nsweeps = 1, bool with_trail = false, bool ec32 = false,
+                   bool out64 = false) {
+    // out64: x_out is written as float64 although VT is float (k_sweep_st only; the caller has checked that it applies)
     // ec32: `ecoarse` really points at float32 data (float64 level 0 above float32 coarse levels; k_sweep0m only)
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
@@ -504,7 +507,8 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         Prof p(c, VOF_K_GS, l, (coef_bytes(c, l) + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C + b(3) + x(3) in, x(3) out
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
         if (geoB && c->sweep_st && !ecoarse && l > 0 && c->cfmt == 2) {   // packed bfloat16 stencils: the kernel with the decoupled coefficient stream
-            k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>((const uint32_t*)lv.C, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+            if (out64) k_sweep_st<CoefB16, VT, double><<<g, GeoB::THREADS, lds, c->stream>>>((const uint32_t*)lv.C, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active);
+            else k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>((const uint32_t*)lv.C, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
             return;
         }
         CDISPATCH(c, l, {
@@ -519,7 +523,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
 template <typename VT>
 VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
                    const int* active, const VT* ecoarse = nullptr, bool allow_swap = false, bool final_smooth = false,
-                   bool ec32 = false) {
+                   bool ec32 = false, bool out64 = false) {
     // Returns the buffer that holds the result: `x`, or `tmp` when allow_swap is set and the last out-of-place sweep
     // ended there (saves a device-to-device copy on the coarse levels).
     // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
@@ -554,7 +558,8 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
         // the cycle's very last pass also delivers the Krylov product of its result, if one was requested
         const bool trail = final_smooth && s == npass - 1 && c->trail_set && c->trail_enabled && l == 0 &&
                            std::is_same<VT, double>::value && sweep0m_usable(c) && src != nullptr;
-        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns, trail, ec32);
+        sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns, trail, ec32,
+                          out64 && s == npass - 1);
         left -= ns;
         src = dst;
         dst = (dst == x) ? tmp : x;
@@ -650,16 +655,24 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
             resrestrict_fine_t<double, float>(c, x, b, (float*)nx.b, np, active);
             float* fx = (float*)nx.x;
             float* ft = (float*)nx.x2;
+            // The last visit of level 1 hands its result up as float64 when its last operation is a k_sweep_st sweep (a regular
+            // stored level with post-smoothing): 12 more bytes per level-1 point written there, but the pass above then reads
+            // the correction as it does in the all-float64 cycle - measured: interpolating from float32 rows costs that pass
+            // 6 % (5 ms per step at 255 pairs), widening the stores of the level-1 sweep costs 1 ms
+            const int nu2c = c->prm.nu_post_coarse > 0 ? c->prm.nu_post_coarse : c->prm.nu_post;
+            const bool can64 = 1 < last && !(c->tail_first == 1 && tail_prepare(c)) && c->L[1].C != nullptr && c->sweep_st &&
+                               c->geo_b_stored && c->cfmt == 2 && nu2c > 0;
+            const int visits = (c->prm.w_cycle_level == 0 && 1 < last) ? (c->prm.w_cycle_visits > 0 ? c->prm.w_cycle_visits : 2) : 1;
+            c->emit64 = can64 && visits == 1;
             float* fe = vcycle_t<float>(c, 1, fx, ft, (const float*)nx.b, np, active, true);
-            if (c->prm.w_cycle_level == 0 && 1 < last) {
-                const int visits = c->prm.w_cycle_visits > 0 ? c->prm.w_cycle_visits : 2;
-                for (int v = 1; v < visits; ++v) {
-                    float* other = (fe == fx) ? ft : fx;
-                    fe = vcycle_t<float>(c, 1, fe, other, (const float*)nx.b, np, active, false);
-                }
+            for (int v = 1; v < visits; ++v) {
+                float* other = (fe == fx) ? ft : fx;
+                c->emit64 = can64 && v == visits - 1;
+                fe = vcycle_t<float>(c, 1, fe, other, (const float*)nx.b, np, active, false);
             }
+            c->emit64 = false;
             return smooth_level_t<double>(c, 0, x, tmp, b, nu2, false, true, np, active, (const double*)fe, /*allow_swap=*/true,
-                                          /*final_smooth=*/true, /*ec32=*/true);
+                                          /*final_smooth=*/true, /*ec32=*/!can64);
         }
     }
     if (resu) {
@@ -681,7 +694,10 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
             ec = vcycle_t<VT>(c, l + 1, ec, other, (const VT*)nx.b, np, active, false);
         }
     }
-    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/true, /*final_smooth=*/l == 0);
+    // (level 1 under a float64 level 0, vcycle_precision 3: the last post-smoothing sweep writes the result as float64)
+    const bool out64 = c->emit64 && l == 1 && std::is_same<VT, float>::value && nu2 > 0;
+    return smooth_level_t<VT>(c, l, x, tmp, b, nu2, false, true, np, active, ec, /*allow_swap=*/true, /*final_smooth=*/l == 0,
+                              /*ec32=*/false, out64);
 }
 
 template <typename VT> int direct_apply_t(vof_ctx* c, VT* z, const VT* r, int np);   // direct preconditioner, below

@@ -2103,10 +2103,11 @@ __global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, i
 //  * the point update reads its neighbours row by row, so that two coefficient sets fit the register budget of 10 waves
 //    per CU.
 // ==========================================================================================
-template <typename CT, typename VT>
+// OT: storage type of x_out (double for the float32 level whose result the float64 level above interpolates)
+template <typename CT, typename VT, typename OT = VT>
 __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, int TI,
                                                                int po, int nx, int ny, int nz, const VT* __restrict__ x_in,
-                                                               VT* __restrict__ x_out, const VT* __restrict__ b,
+                                                               OT* __restrict__ x_out, const VT* __restrict__ b,
                                                                const int* __restrict__ active) {
     typedef GeoB G;
     typedef typename CoefFmt<CT>::word_t word_t;
@@ -2125,7 +2126,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
     const int qs = bx * OUT - SW_HALO;
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
     const VT* xin = x_in ? x_in + off : nullptr;
-    VT* xout = x_out + off;
+    OT* xout = x_out + off;
     const VT* bp = b + off;
     const CLay L(ni, nj);
     const word_t* Cp = C + (size_t)pair * PLANES * L.plane;
@@ -2230,9 +2231,9 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
             const bool rowok = m_row ? okB : okA;
             if (m_st && rowok) {
                 const int slot = m_row ? slotB : slotA;
-                VT* orow = xout + (size_t)(m_row ? pB : pA) * nj + m_g;
+                OT* orow = xout + (size_t)(m_row ? pB : pA) * nj + m_g;
                 const VT* lrow = xs + slot * 3 * W + m_lds;
-                orow[0] = lrow[0]; orow[npts] = lrow[W]; orow[2 * npts] = lrow[2 * W];
+                orow[0] = (OT)lrow[0]; orow[npts] = (OT)lrow[W]; orow[2 * npts] = (OT)lrow[2 * W];
             }
         }
         // (2) rows e + 2, e + 3 -> registers (moved into the ring in (5)), then the next step's point
