@@ -1090,32 +1090,35 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     const size_t len = 3 * f.npts;
     hipStream_t s = c->stream;
     // right-hand side and its norm
-    {
+    {   // b and the block partial sums of (b, b) in one pass
         Prof p(c, VOF_K_RHS, 0);
-        k_rhs<<<grid2d(f.ni, f.nj, np), blk2d, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb, c->pp);
+        k_rhs_norm<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb, c->partials, c->pp);
     }
-    { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kb, c->kb, nullptr, nullptr, len, c->partials, nullptr); }
     { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_BNORM><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     // initial guess (OF.py:799-802: constants, in pixels/frame) and initial residual
     double sx = P.delta_t / P.delta_x;
     bool zero_guess = (P.initial_v_x == 0.0 && P.initial_v_y == 0.0 && P.initial_remodelling == 0.0);
+    int nb0 = c->nblk;   // per-pair partial sums of (r0, r0): from the zero guess they are those of (b, b), still in place
     if (c->guess_src) {   // warm start from the solution of a neighbouring, already solved pair (cf. OF.py:803-806)
         { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len);
           k_gather_guess<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->warm_x, c->guess_src, len, f.npts, P.initial_v_x * sx, P.initial_v_y * sx,
                                                       P.initial_remodelling); }
-        residual_d(c, c->kx, c->kb, c->kr, np, nullptr);
+        nb0 = residual_d(c, c->kx, c->kb, c->kr, np, nullptr, 1);   // r0 = b - A x0 with the partial sums of (r0, r0)
     } else if (zero_guess) {
         HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)np * len * sizeof(double), s));
         HIPCHK(hipMemcpyAsync(c->kr, c->kb, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
     } else {
         { Prof p(c, VOF_K_VECTOR, 0); k_fill<<<dim3(c->nblk, np), 256, 0, s>>>(c->kx, f.npts, P.initial_v_x * sx, P.initial_v_y * sx, P.initial_remodelling); }
-        residual_d(c, c->kx, c->kb, c->kr, np, nullptr);
+        nb0 = residual_d(c, c->kx, c->kb, c->kr, np, nullptr, 1);
     }
     HIPCHK(hipMemcpyAsync(c->krh, c->kr, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemsetAsync(c->kp, 0, (size_t)np * len * sizeof(double), s));
     HIPCHK(hipMemsetAsync(c->kv, 0, (size_t)np * len * sizeof(double), s));
-    { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kr, nullptr, nullptr, len, c->partials, nullptr); }
-    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R0><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
+    if (!nb0) {   // the operator kernel in use does not fuse the norm
+        Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kr, nullptr, nullptr, len, c->partials, nullptr);
+        nb0 = c->nblk;
+    }
+    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R0><<<np, 64, 0, s>>>(c->sc, c->partials, nb0, c->active, P.rtol, P.max_iterations); }
 
     // krylov_method: 0 = BiCGStab only (the reference's 'bcgs'); 1 = GMRES only; 2 = BiCGStab, and restarted GMRES for
     // the pairs that have not met the tolerance after `fallback_after` iterations (or broke down)
@@ -1203,12 +1206,11 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
             if (int rc = independent_residual()) return rc;
     }
     // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
-    { Prof p(c, VOF_K_FUNCTIONALS, 0);
-      k_functionals<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, P.speed_alpha,
-                                                  P.remodelling_alpha, P.reference_quirks, c->kx, c->partials, c->pp);
+    { Prof p(c, VOF_K_FINALIZE, 0);   // one pass over the solution: outputs + functionals
+      k_finalize_functionals<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), f.ni, f.nj, P.speed_alpha, P.remodelling_alpha,
+                                                           P.reference_quirks, c->kx, P.delta_x / P.delta_t, vx, vy, gm, speed,
+                                                           c->partials, c->pp);
       k_sum3<<<np, 64, 0, s>>>(c->partials, c->nblk, c->func3); }
-    { Prof p(c, VOF_K_FINALIZE, 0);
-      k_finalize<<<grid2d(c->Ni, c->Nj, np), blk2d, 0, s>>>(c->kx, f.ni, f.nj, P.delta_x / P.delta_t, vx, vy, gm, speed, c->pp); }
     HIPCHK(hipGetLastError());
     if (stats) {
         HIPCHK(hipMemcpyAsync(c->h_sc, c->sc, np * sizeof(PairScalars), hipMemcpyDeviceToHost, s));

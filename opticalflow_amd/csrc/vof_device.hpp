@@ -1003,6 +1003,77 @@ __global__ __launch_bounds__(RBLK) void k_dot2(const double* __restrict__ a1, co
     block_store_partials(s0, s1, 0.0, partials, a2 ? 2 : 1, gridDim.x, pair, blockIdx.x);
 }
 
+// k_rhs with the block partial sums of (b, b): the right-hand side and its norm in one pass
+__global__ __launch_bounds__(RBLK) void k_rhs_norm(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj,
+                                                   double* __restrict__ b, double* __restrict__ partials,
+                                                   const PairParam* __restrict__ pp) {
+    const int pair = blockIdx.y;
+    const size_t npts = (size_t)ni * nj;
+    const double* I0 = frames + (size_t)(pp ? pp[pair].frame : pair) * frame_stride;
+    double* bp = b + (size_t)pair * 3 * npts;
+    double s0 = 0.0;
+    for (size_t t = (size_t)blockIdx.x * RBLK + threadIdx.x; t < npts; t += (size_t)gridDim.x * RBLK) {
+        const int p = (int)(t / nj), q = (int)(t - (size_t)p * nj);
+        const double* I = I0 + (size_t)(p + 1) * Nj + (q + 1);
+        const double* J = I + frame_stride;
+        const double P = I[0];
+        const double dxt = (J[Nj] - J[-Nj] - I[Nj] + I[-Nj]) / 2;  // OF.py:815-816
+        const double dyt = (J[1] - J[-1] - I[1] + I[-1]) / 2;      // OF.py:818-819
+        const double dt = J[0] - I[0];                              // OF.py:821-823
+        const double b0 = -P * dxt, b1 = -P * dyt, b2 = -dt;
+        bp[t] = b0; bp[npts + t] = b1; bp[2 * npts + t] = b2;
+        s0 += b0 * b0 + b1 * b1 + b2 * b2;
+    }
+    block_store_partials(s0, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
+}
+
+// Epilogue in one pass: k_finalize (unpack + mirror boundary + unit scaling + speed, OF.py:1159-1166, 1189-1191) and the
+// functionals of k_functionals (OF.py:1167-1183) - the solution is read once.  Grid-stride over the full Ni x Nj output grid.
+__global__ __launch_bounds__(RBLK) void k_finalize_functionals(const double* __restrict__ frames, size_t frame_stride, int ni, int nj,
+                                                               double alpha, double beta, int quirks, const double* __restrict__ x,
+                                                               double vscale, double* __restrict__ vx, double* __restrict__ vy,
+                                                               double* __restrict__ gm, double* __restrict__ speed,
+                                                               double* __restrict__ partials, const PairParam* __restrict__ pp) {
+    const int pair = blockIdx.y;
+    const int Ni = ni + 2, Nj = nj + 2;
+    const size_t npts = (size_t)ni * nj, Npts = (size_t)Ni * Nj;
+    const double* xu = x + (size_t)pair * 3 * npts;
+    const double* xw = xu + npts;
+    const double* xg = xw + npts;
+    int fidx = pair;
+    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
+    const double* I = frames + (size_t)fidx * frame_stride;
+    const double* J = I + frame_stride;
+    const size_t obase = (size_t)(pp ? pp[pair].out : pair) * Npts;
+    double sL = 0, sS = 0, sR = 0;
+    for (size_t t = (size_t)blockIdx.x * RBLK + threadIdx.x; t < Npts; t += (size_t)gridDim.x * RBLK) {
+        const int i = (int)(t / Nj), j = (int)(t - (size_t)i * Nj);
+        const int p = fold(i - 1, ni), q = fold(j - 1, nj);
+        const size_t c = (size_t)p * nj + q;
+        const double u0 = xu[c], w0 = xw[c], g0 = xg[c];
+        const double u = u0 * vscale, w = w0 * vscale;
+        vx[obase + t] = u; vy[obase + t] = w; gm[obase + t] = g0;
+        if (speed) speed[obase + t] = sqrt(u * u + w * w);
+        if (i >= 1 && i <= ni && j >= 1 && j <= nj) {   // interior pixel (p, q) = (i - 1, j - 1): its functional terms
+            PixCoef k = pix_coef(I, Nj, p, q, quirks);
+            const double dt = J[(size_t)(p + 1) * Nj + q + 1] - k.P;
+            // BC-fixed field value at interior offset: plain fold (no corner factor)
+            const int pm = fold(p - 1, ni), pq = fold(p + 1, ni), qm = fold(q - 1, nj), qp = fold(q + 1, nj);
+            const size_t a_m = (size_t)pm * nj + q, a_p = (size_t)pq * nj + q;
+            const size_t b_m = (size_t)p * nj + qm, b_p = (size_t)p * nj + qp;
+            const double dux = (xu[a_p] - xu[a_m]) / 2, dwx = (xw[a_p] - xw[a_m]) / 2, dgx = (xg[a_p] - xg[a_m]) / 2;
+            const double duy = quirks ? dux : (xu[b_p] - xu[b_m]) / 2;
+            const double dwy = quirks ? dwx : (xw[b_p] - xw[b_m]) / 2;
+            const double dgy = quirks ? dgx : (xg[b_p] - xg[b_m]) / 2;
+            const double e = dt + u0 * k.Dx + w0 * k.Dy + k.P * dux + k.P * dwy - g0;
+            sL += e * e;
+            sS += dux * dux + duy * duy + dwx * dwx + dwy * dwy;
+            sR += dgx * dgx + dgy * dgy;
+        }
+    }
+    block_store_partials(sL, alpha * sS, beta * sR, partials, 3, gridDim.x, pair, blockIdx.x);
+}
+
 // The BiCGStab vector updates process two elements per lane and iteration (16-B accesses on the float64
 // vectors) when the vector length is even; `len2` = len / 2 (or 0 to force the scalar path).
 template <typename T> struct Vec2;
