@@ -117,7 +117,9 @@ struct vof_ctx {
     bool geo_b_fine = false, geo_b_stored = true;   // strip geometry of the fused sweep per level class
     bool fuse_prolong = true;   // level 0: coarse-grid correction interpolated inside the first post-sweep
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
-    bool sweep_st = true;       // stored levels, 32-bit stencils: k_sweep_st (VOF_SWEEP_ST=0: the generic k_sweep)
+    bool sweep_st = true;       // stored levels, packed bfloat16 stencils: k_sweep_st (VOF_SWEEP_ST=0: the generic k_sweep)
+    bool fold_stored = false;   // ... with the coarse-grid correction interpolated inside the first post-sweep (VOF_FOLD_STORED=1; measured:
+                                // the sweep gets slower by what the stand-alone prolongation kernel costs, so that one stays)
     bool fuse_resu = true;      // stored levels: coarse right-hand side from the last pre-smoothing sweep's update (k_resrestrict_u;
                                 // VOF_FUSE_RESU=0: stand-alone residual + restriction kernels)
     bool stream_apply = true;   // LDS-streaming level-0 operator kernel with fused reductions (false: simple kernel)
@@ -303,7 +305,7 @@ template <typename XT, typename BT, typename YT>
 void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np, const int* active,
                   const double* dotvec = nullptr, int want_yy = 0) {
     Level& lv = c->L[0];
-    const double bytes = (8.0 + 3.0 * sizeof(XT) + 3.0 * sizeof(YT) + (mode ? 3.0 * sizeof(BT) : 0.0) +
+    const double bytes = (8.0 + 3.0 * sizeof(XT) + (y ? 3.0 * sizeof(YT) : 0.0) + (mode ? 3.0 * sizeof(BT) : 0.0) +
                           (dotvec ? 24.0 : 0.0)) * lv.npts;
     Prof p(c, VOF_K_APPLY0, 0, bytes);
     if (c->stream_apply) {
@@ -358,7 +360,10 @@ int krylov_apply(vof_ctx* c, const void* y, double* out, int np, const int* acti
     else apply_fine_t<double, double, double>(c, (const double*)y, nullptr, out, 0, np, active, fuse ? dotvec : nullptr, fuse ? want_yy : 0);
     return fuse ? apply_grid(c, np).nblk : 0;
 }
+// (out == nullptr with want_norm: only the norm is wanted - the streaming kernel then writes nothing; returns 0 if that is
+// not possible, and the caller falls back to a residual vector)
 int residual_d(vof_ctx* c, const double* x, const double* b, double* out, int np, const int* active, int want_norm = 0) {
+    if (!out && !(want_norm && c->stream_apply && !c->L[0].C)) return 0;
     if (c->L[0].C) { apply_stored_t<double>(c, 0, x, b, out, 1, np, active); return 0; }
     const bool fuse = c->stream_apply && want_norm;
     apply_fine_t<double, double, double>(c, x, b, out, 1, np, active, nullptr, fuse ? 1 : 0);
@@ -421,6 +426,11 @@ void coarse_solve_t(vof_ctx* c, const VT* r, VT* e, int np, const int* active) {
 // k_sweep0m (merged colours, 16-byte accesses, up to two sweeps per pass) needs float64 vectors and an even row length
 inline bool sweep0m_usable(const vof_ctx* c) {
     return c->sweep0m && c->sweep0 && c->fused && !c->geo_b_fine && !c->vfloat && (c->L[0].nj % 2 == 0) && c->L[0].C == nullptr;
+}
+
+// k_sweep_st: stored levels with packed bfloat16 stencils and the 128-column strip geometry
+inline bool sweep_st_usable(const vof_ctx* c, int l) {
+    return l > 0 && c->L[l].C != nullptr && c->sweep_st && c->geo_b_stored && c->cfmt == 2;
 }
 
 // One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
@@ -504,11 +514,18 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         }
         else k_sweep<SweepFine, GeoA, VT><<<g, GeoA::THREADS, lds, c->stream>>>(pol, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
     } else {
-        Prof p(c, VOF_K_GS, l, (coef_bytes(c, l) + (x_in ? 9.0 : 6.0) * vs) * lv.npts);   // C + b(3) + x(3) in, x(3) out
+        Prof p(c, VOF_K_GS, l, (coef_bytes(c, l) + (x_in ? 9.0 : 6.0) * vs) * lv.npts + ebytes);   // C + b(3) + x(3) in, x(3) out (+ coarse e)
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT);
-        if (geoB && c->sweep_st && !ecoarse && l > 0 && c->cfmt == 2) {   // packed bfloat16 stencils: the kernel with the decoupled coefficient stream
-            if (out64) k_sweep_st<CoefB16, VT, double><<<g, GeoB::THREADS, lds, c->stream>>>((const uint32_t*)lv.C, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active);
-            else k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>((const uint32_t*)lv.C, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active);
+        if (sweep_st_usable(c, l)) {   // packed bfloat16 stencils: the kernel with the decoupled coefficient stream
+            const uint32_t* Cw = (const uint32_t*)lv.C;
+            if (ecoarse) {   // the sweep starts from x_in + P ecoarse (coarse rows through a 3-row LDS ring)
+                const size_t lds_e = lds + (size_t)9 * (W / 2 + 2) * sizeof(VT);
+                if (out64) k_sweep_st<CoefB16, VT, double, true><<<g, GeoB::THREADS, lds_e, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active, ecoarse, nci, ncj);
+                else k_sweep_st<CoefB16, VT, VT, true><<<g, GeoB::THREADS, lds_e, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+            } else {
+                if (out64) k_sweep_st<CoefB16, VT, double><<<g, GeoB::THREADS, lds, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active, nullptr, 0, 0);
+                else k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, nullptr, 0, 0);
+            }
             return;
         }
         CDISPATCH(c, l, {
@@ -529,8 +546,8 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
     // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
     // into the first sweep (coarse rows streamed through LDS); otherwise the prolongation kernel runs first.
     const size_t bytes = (size_t)np * 3 * c->L[l].npts * sizeof(VT);
-    const bool fold = ecoarse && nu > 0 && c->fused && c->fuse_prolong && l == 0 && c->L[0].C == nullptr &&
-                      !c->geo_b_fine && !from_zero;
+    const bool fold = ecoarse && nu > 0 && c->fused && c->fuse_prolong && !from_zero &&
+                      ((l == 0 && c->L[0].C == nullptr && !c->geo_b_fine) || (sweep_st_usable(c, l) && c->fold_stored));
     if (ecoarse && !fold) {
         prolong_add_level_t<VT>(c, l, x, ecoarse, np, active);
         ecoarse = nullptr;
@@ -1171,15 +1188,17 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     };
     if (int rc = bicg_loop(bicg_limit)) return rc;
     // independent residual (OF.py:1150-1151): ||b - A x|| recomputed from x for every pair
-    auto independent_residual = [&]() -> int {
+    // (keep == false: only the norm, no residual vector - it is needed again only if a pair has to be restarted)
+    auto independent_residual = [&](bool keep) -> int {
         c->cur_units = np;
-        int nb3 = residual_d(c, c->kx, c->kb, c->kt, np, nullptr, 1);
+        int nb3 = keep ? 0 : residual_d(c, c->kx, c->kb, nullptr, np, nullptr, 1);
+        if (!nb3) nb3 = residual_d(c, c->kx, c->kb, c->kt, np, nullptr, 1);
         if (!nb3) { Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kt, nullptr, nullptr, len, c->partials, nullptr); nb3 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_FINAL><<<np, 64, 0, s>>>(c->sc, c->partials, nb3, c->active, P.rtol, P.max_iterations); }
         HIPCHK(hipGetLastError());
         return 0;
     };
-    if (int rc = independent_residual()) return rc;
+    if (int rc = independent_residual(false)) return rc;
     // The stopping rule is evaluated on the independent residual.  BiCGStab tests its recursively updated residual, which
     // drifts from the true one (by rounding; visibly so near the attainable accuracy): pairs it declared converged whose
     // recomputed residual misses the tolerance are restarted from that residual (r = r^ = b - A x, p = v = 0), which a
@@ -1190,11 +1209,12 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
             int nact = count_active(c, np);
             if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
             if (nact == 0) break;
+            if (int rc = independent_residual(true)) return rc;   // the restart needs the residual vector itself (rare)
             c->cur_units = nact;
             { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5);
               k_restart_vectors<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->krh, c->kp, c->kv, c->kt, len, c->active); }
             if (int rc = bicg_loop(std::min(bicg_limit, 8))) return rc;
-            if (int rc = independent_residual()) return rc;
+            if (int rc = independent_residual(false)) return rc;
         }
     }
     if (P.krylov_method != 0) {
@@ -1203,7 +1223,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         int handed_over = 0;
         if (int rc = gmres_phase(c, np, &handed_over)) return rc;
         if (handed_over)
-            if (int rc = independent_residual()) return rc;
+            if (int rc = independent_residual(false)) return rc;
     }
     // functionals (OF.py:1167-1183) and epilogue (OF.py:1159-1166, 1189-1191)
     { Prof p(c, VOF_K_FINALIZE, 0);   // one pass over the solution: outputs + functionals
@@ -1381,6 +1401,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_FUSE_PROLONG")) c->fuse_prolong = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_RESU")) c->fuse_resu = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP_ST")) c->sweep_st = e[0] != '0';
+    if (const char* e = getenv("VOF_FOLD_STORED")) c->fold_stored = e[0] != '0';
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';

@@ -196,6 +196,14 @@ __device__ __forceinline__ void add_raw_block(const PixCoef& k, double alpha, do
     }
 }
 
+// Entries r * 3 + c of the raw block of offset (oi, oj) that add_raw_block can set (bit mask)
+__host__ __device__ constexpr unsigned raw_block_mask(int oi, int oj) {
+    return (oi == 0 && oj == 0) ? 0x1DBu                 // {0, 1, 3, 4, 6, 7, 8}
+         : (oj == 0)            ? 0x15Fu                 // {0, 1, 2, 3, 4, 6, 8}
+         : (oi == 0)            ? 0x1BBu                 // {0, 1, 3, 4, 5, 7, 8}
+                                : 0x00Au;                // {1, 3}
+}
+
 // Folded block of offset (oi, oj) at interior point (p, q): the ghost couplings are added onto the
 // interior point they mirror to.  The target (p+oi, q+oj) must be inside the grid.
 __device__ __forceinline__ void folded_block(const PixCoef& k, double alpha, double beta, int p, int q, int ni,
@@ -817,7 +825,12 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
                             if (Dq < 0 || Dq >= ncj) continue;
                             const AT w = (AT)(wf * wgi * pweight(gq, Dq, ncj));
 #pragma unroll
-                            for (int t = 0; t < 9; ++t) acc[(a + 1) * 3 + (b + 1)][t] += w * blk[t];
+                            for (int t = 0; t < 9; ++t) {
+                                // level 0: only 43 of the 81 entries of a point's nine blocks can be non-zero (OF.py:843-960;
+                                // folding a ghost block onto its mirror keeps the pattern) - the others are skipped at compile time
+                                if (LEVEL0 && !((raw_block_mask(oi, oj) >> t) & 1u)) continue;
+                                acc[(a + 1) * 3 + (b + 1)][t] += w * blk[t];
+                            }
                         }
                     }
                 }
@@ -2175,16 +2188,22 @@ __global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, i
 //    per CU.
 // ==========================================================================================
 // OT: storage type of x_out (double for the float32 level whose result the float64 level above interpolates)
-template <typename CT, typename VT, typename OT = VT>
+// EC: the sweep starts from x_in + P ecoarse (bilinear interpolation of the coarse-grid correction, as k_prolong_add computes it):
+// the coarse rows go through a 3-row LDS ring, one new row per step requested a step ahead, and are added to the fine rows on
+// their way into the x ring - the separate prolongation pass (read + write of x) disappears
+template <typename CT, typename VT, typename OT = VT, bool EC = false>
 __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, int TI,
                                                                int po, int nx, int ny, int nz, const VT* __restrict__ x_in,
                                                                OT* __restrict__ x_out, const VT* __restrict__ b,
-                                                               const int* __restrict__ active) {
+                                                               const int* __restrict__ active, const VT* __restrict__ ecoarse, int nci,
+                                                               int ncj) {
     typedef GeoB G;
     typedef typename CoefFmt<CT>::word_t word_t;
     constexpr int W = G::W, OUT = G::OUT, THREADS = G::THREADS, PLANES = CoefFmt<CT>::PLANES;
     extern __shared__ double sw_lds[];
     VT* xs = reinterpret_cast<VT*>(sw_lds);                                                     // [SW_RING][3][W]
+    constexpr int CRW = W / 2 + 2;                                                              // coarse ring width
+    VT* cr = xs + SW_RING * 3 * W;                                                              // [3][3][CRW] (EC)
     const unsigned nblocks = (unsigned)nx * ny * nz;
     unsigned lb = blockIdx.x;
     if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
@@ -2221,14 +2240,53 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
     const unsigned ccq = (unsigned)((size_t)(qc & 1) * L.sub + (size_t)(qc >> 1));   // column part of the stencil index
     const unsigned bcol = (unsigned)qc;
     // ---- cooperative load-in / write-out of 2 rows x 3 fields x W columns per step: thread <-> (row, column) of the two
-    // rows (2 x 136 of the 320 threads), the three fields are the unrolled index
-    const int m_row = tid >= W ? 1 : 0, m_col = tid - m_row * W;
-    const bool m_on = tid < 2 * W;
-    const int m_q = qs + m_col;
-    const bool m_ld = m_on && m_q >= 0 && m_q < nj;
-    const bool m_st = m_ld && m_col >= SW_HALO && m_col < SW_HALO + OUT;
-    const unsigned m_g = m_ld ? (unsigned)m_q : 0u;
-    const int m_lds = sw_cs<G>(m_on ? m_col : 0);
+    // rows (2 x 136 of the 320 threads), the three fields are the unrolled index.  The mapping is RECOMPUTED where it is used,
+    // from a thread index the compiler cannot see through: as loop invariants these values sat in registers across the point
+    // update, where the two coefficient sets leave no room (a spill reload is a scratch load, and waiting for one drains the
+    // whole coefficient stream).
+    auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    struct XMap { int row, col, q, lds; unsigned g; bool on, ld, st; };
+    auto xmap = [&](const int t) {
+        XMap m;
+        m.row = t >= W ? 1 : 0; m.col = t - m.row * W;
+        m.on = t < 2 * W;
+        m.q = qs + m.col;
+        m.ld = m.on && m.q >= 0 && m.q < nj;
+        m.st = m.ld && m.col >= SW_HALO && m.col < SW_HALO + OUT;
+        m.g = m.ld ? (unsigned)m.q : 0u;
+        m.lds = sw_cs<G>(m.on ? m.col : 0);
+        return m;
+    };
+    // coarse-correction ring: thread <-> (field, coarse column) of the row requested in a step; fine column q interpolates
+    // from the coarse columns (q >> 1) and (q >> 1) + 1
+    const size_t ncpts = (size_t)nci * ncj;
+    const VT* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
+    const int cqs = qs >> 1;                                   // coarse column of ring column 0 (qs is even)
+    struct CMap { int f, c; unsigned g; bool on, cv; };
+    auto cmap = [&](const int t) {
+        CMap m;
+        const int f = t / CRW;
+        m.c = t - f * CRW;
+        m.on = EC && t < 3 * CRW;
+        m.f = m.on ? f : 0;
+        const int crq = cqs + m.c;
+        m.cv = m.on && crq >= 0 && crq < ncj;
+        m.g = m.cv ? (unsigned)crq : 0u;
+        return m;
+    };
+    auto cr_slot = [](int k) { return ((k % 3) + 3) % 3; };
+    if (EC) {   // prologue: the two coarse rows the first step's fine rows need
+        const CMap cm = cmap(tid);
+        const int k0 = (p0 - 2) >> 1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int k = k0 + d;
+            VT v = (VT)0;
+            if (cm.cv && k >= 0 && k < nci) v = ec[(size_t)cm.f * ncpts + (size_t)k * ncj + cm.g];
+            if (cm.on) cr[(cr_slot(k) * 3 + cm.f) * CRW + cm.c] = v;
+        }
+        __syncthreads();
+    }
     const int sro = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
     const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
     const bool uni = wave < 4;                           // colour waves: the stage's row is wave-uniform
@@ -2294,32 +2352,41 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
         constexpr int JC = decltype(jtag)::value;
         const int slotB = slotA + 1;
         const bool do_load = FAST ? true : (e + 2 <= TI + 1);
+        const XMap m1 = xmap(opaque_tid());
         // (1) write-out of the rows that became final: relative rows e - 10, e - 9
         {
             const int rrA = e - 10, rrB = e - 9, pA = p0 + rrA, pB = p0 + rrB;
             const bool okA = FAST ? true : (rrA >= 0 && rrA < TI && pA >= 0 && pA < ni);
             const bool okB = FAST ? true : (rrB >= 0 && rrB < TI && pB >= 0 && pB < ni);
-            const bool rowok = m_row ? okB : okA;
-            if (m_st && rowok) {
-                const int slot = m_row ? slotB : slotA;
-                OT* orow = xout + (size_t)(m_row ? pB : pA) * nj + m_g;
-                const VT* lrow = xs + slot * 3 * W + m_lds;
+            const bool rowok = m1.row ? okB : okA;
+            if (m1.st && rowok) {
+                const int slot = m1.row ? slotB : slotA;
+                OT* orow = xout + (size_t)(m1.row ? pB : pA) * nj + m1.g;
+                const VT* lrow = xs + slot * 3 * W + m1.lds;
                 orow[0] = (OT)lrow[0]; orow[npts] = (OT)lrow[W]; orow[2 * npts] = (OT)lrow[2 * W];
             }
         }
         // (2) rows e + 2, e + 3 -> registers (moved into the ring in (5)), then the next step's point
         VT lx[3] = {(VT)0, (VT)0, (VT)0};
         if (xin) {
-            const int pR = p0 + e + 2 + m_row;
+            const int pR = p0 + e + 2 + m1.row;
             if (FAST) {
-                const VT* irow = xin + (size_t)pR * nj + m_g;
+                const VT* irow = xin + (size_t)pR * nj + m1.g;
                 // (columns outside the grid take the value of a clamped address instead of 0: they only ever meet the zero
                 // coefficients of out-of-grid neighbours, and a select here would be a wait for the load just issued)
                 lx[0] = irow[0]; lx[1] = irow[npts]; lx[2] = irow[2 * npts];
-            } else if (m_ld && do_load && pR >= 0 && pR < ni) {
-                const VT* irow = xin + (size_t)pR * nj + m_g;
+            } else if (m1.ld && do_load && pR >= 0 && pR < ni) {
+                const VT* irow = xin + (size_t)pR * nj + m1.g;
                 lx[0] = irow[0]; lx[1] = irow[npts]; lx[2] = irow[2 * npts];
             }
+        }
+        VT crv = (VT)0;                                   // element of the coarse row the NEXT step needs
+        const int knew = ((p0 + e + 4) >> 1) + 1;
+        const bool kok = knew >= 0 && knew < nci;
+        if (EC) {
+            const CMap cm = cmap(opaque_tid());
+            if (FAST) crv = ec[(size_t)cm.f * ncpts + (size_t)(kok ? knew : 0) * ncj + cm.g];
+            else if (cm.cv && kok) crv = ec[(size_t)cm.f * ncpts + (size_t)knew * ncj + cm.g];
         }
         fetch_point(fast_tag, std::integral_constant<int, 1 - JC>{}, e + 2);
         // (4) the stage of this lane: block Gauss-Seidel update of its point, neighbours read row by row
@@ -2359,9 +2426,36 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
         }
         fetch_diag(fast_tag, e + 2);   // the diagonal block of the next step's point (the registers are free now)
         // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
-        if (do_load && m_on) {
-            VT* lrow = xs + (m_row ? slotB : slotA) * 3 * W + m_lds;
+        const XMap m5 = xmap(opaque_tid());
+        if (do_load && m5.on) {
+            if (EC) {   // + (P e)(pR, q) from the coarse ring; same terms in the same order as k_prolong_add
+                const int pR = p0 + e + 2 + m5.row;
+                if (m5.ld && (FAST || (pR >= 0 && pR < ni))) {
+                    const int cp = pR >> 1;
+                    const bool ipi = (pR & 1) && (cp + 1 < nci);
+                    const bool ipj = (m5.q & 1) && ((m5.q >> 1) + 1 < ncj);
+                    const double wi0 = ipi ? 0.5 : 1.0, wj0 = ipj ? 0.5 : 1.0;
+                    const int ilcq = (m5.q >> 1) - cqs;                    // ring column of (q >> 1)
+                    const VT* c0 = cr + cr_slot(cp) * 3 * CRW + ilcq;
+                    const VT* c1 = cr + cr_slot(cp + 1) * 3 * CRW + ilcq;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        double v = wi0 * wj0 * (double)c0[f * CRW];
+                        if (ipj) v += wi0 * 0.5 * (double)c0[f * CRW + 1];
+                        if (ipi) {
+                            v += 0.5 * wj0 * (double)c1[f * CRW];
+                            if (ipj) v += 0.25 * (double)c1[f * CRW + 1];
+                        }
+                        lx[f] = (VT)((double)lx[f] + v);
+                    }
+                }
+            }
+            VT* lrow = xs + (m5.row ? slotB : slotA) * 3 * W + m5.lds;
             lrow[0] = lx[0]; lrow[W] = lx[1]; lrow[2 * W] = lx[2];
+        }
+        if (EC && do_load) {
+            const CMap cm = cmap(opaque_tid());
+            if (cm.on) cr[(cr_slot(knew) * 3 + cm.f) * CRW + cm.c] = (cm.cv && kok) ? crv : (VT)0;
         }
         slotA = sw_wrap(slotA + 2);
         __syncthreads();
@@ -3254,9 +3348,11 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
                 y1 = (double)b[off + npts + idx] - y1;
                 y2 = (double)b[off + 2 * npts + idx] - y2;
             }
-            y[off + idx] = (YT)y0;
-            y[off + npts + idx] = (YT)y1;
-            y[off + 2 * npts + idx] = (YT)y2;
+            if (y) {   // (nullptr: only the reductions are wanted)
+                y[off + idx] = (YT)y0;
+                y[off + npts + idx] = (YT)y1;
+                y[off + 2 * npts + idx] = (YT)y2;
+            }
             if (dotvec) {
                 s0 += y0 * dotvec[off + idx] + y1 * dotvec[off + npts + idx] + y2 * dotvec[off + 2 * npts + idx];
                 if (want_yy) s1 += y0 * y0 + y1 * y1 + y2 * y2;
