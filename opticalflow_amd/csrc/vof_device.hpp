@@ -3283,8 +3283,12 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
     // image ring local column li <-> full-image column q0 + li; point q uses li = col, col+1, col+2
     double s0 = 0.0, s1 = 0.0;
     const int nsteps = TI / 2;
+    BT bn0 = (BT)0, bn1 = (BT)0, bn2 = (BT)0;   // b and the dot partner of this thread's point of the NEXT step (loaded a step ahead)
+    double dn0 = 0.0, dn1 = 0.0, dn2 = 0.0;
     for (int s = -2; s < nsteps; ++s) {
         const int r = 2 * s;
+        const BT bc0 = bn0, bc1 = bn1, bc2 = bn2;
+        const double dc0 = dn0, dc1 = dn1, dc2 = dn2;
         // ---- global loads of relative row r + 3 + half into registers
         const int rl = r + 3 + half, pl = p0 + rl;
         const bool row_ld = rl <= TI && pl >= 0 && pl < ni;
@@ -3302,6 +3306,14 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
             const double* ir = img + (size_t)(pl + 1) * Nj;
             if (q0 + col <= nj + 1) li0 = ir[q0 + col];
             if (col < 2 && q0 + 128 + col <= nj + 1) li1 = ir[q0 + 128 + col];
+        }
+        {   // b / dot partner of the row this thread computes in the next step
+            const int rcn = r + 2 + half, pn = p0 + rcn;
+            if (s + 1 >= 0 && rcn < TI && pn < ni && col_ok) {
+                const size_t idn = (size_t)pn * nj + q;
+                if (MODE == 1) { bn0 = b[off + idn]; bn1 = b[off + npts + idn]; bn2 = b[off + 2 * npts + idn]; }
+                if (dotvec) { dn0 = dotvec[off + idn]; dn1 = dotvec[off + npts + idn]; dn2 = dotvec[off + 2 * npts + idn]; }
+            }
         }
         // ---- compute relative row r + half
         const int rc = r + half, p = p0 + rc;
@@ -3344,9 +3356,9 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
             y2 += (-1 - 4 * beta) * n.g[4] + k.Dx * n.u[4] + k.Dy * n.w[4];
             const size_t idx = (size_t)p * nj + q;
             if (MODE == 1) {
-                y0 = (double)b[off + idx] - y0;
-                y1 = (double)b[off + npts + idx] - y1;
-                y2 = (double)b[off + 2 * npts + idx] - y2;
+                y0 = (double)bc0 - y0;
+                y1 = (double)bc1 - y1;
+                y2 = (double)bc2 - y2;
             }
             if (y) {   // (nullptr: only the reductions are wanted)
                 y[off + idx] = (YT)y0;
@@ -3354,7 +3366,7 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
                 y[off + 2 * npts + idx] = (YT)y2;
             }
             if (dotvec) {
-                s0 += y0 * dotvec[off + idx] + y1 * dotvec[off + npts + idx] + y2 * dotvec[off + 2 * npts + idx];
+                s0 += y0 * dc0 + y1 * dc1 + y2 * dc2;
                 if (want_yy) s1 += y0 * y0 + y1 * y1 + y2 * y2;
             } else if (want_yy) {
                 s0 += y0 * y0 + y1 * y1 + y2 * y2;
@@ -3432,8 +3444,11 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
     const bool e_on = tid < 3 * RR_CO && ecq < ncj;
     const size_t ncpts = (size_t)nci * ncj;
     const int nsteps = TI / 2 + 1;                      // fine rows p0 .. p0 + TI (relative 0 .. TI)
+    BT bn0 = (BT)0, bn1 = (BT)0, bn2 = (BT)0;           // b of this thread's point of the NEXT step (loaded a step ahead: used
+                                                        // at the point of use, its latency was exposed in every step)
     for (int s = -2; s <= nsteps + 1; ++s) {
         const int r = 2 * s;
+        const BT bc0 = bn0, bc1 = bn1, bc2 = bn2;
         // ---- restriction of coarse row k = s - 2 (fine relative rows 2k, 2k+1, 2k+2), computed in earlier steps
         {
             const int k = s - 2;
@@ -3475,6 +3490,13 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
             if (fc0 >= 0 && fc0 <= nj + 1) li0 = ir[fc0];
             if (col < 2 && fc1 >= 0 && fc1 <= nj + 1) li1 = ir[fc1];
         }
+        {   // b of the row this thread computes in the next step
+            const int rcn = r + 2 + half, pn = p0 + rcn;
+            if (s + 1 >= 0 && rcn <= TI && pn >= 0 && pn < ni && col_ok) {
+                const size_t idn = (size_t)pn * nj + q;
+                bn0 = b[off + idn]; bn1 = b[off + npts + idn]; bn2 = b[off + 2 * npts + idn];
+            }
+        }
         // ---- fine residual of relative row r + half -> LDS residual ring
         const int rc = r + half, p = p0 + rc;
         if (s >= 0 && rc <= TI) {
@@ -3515,10 +3537,9 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_resrestrict0(
                 y0 += (P * (k.Dxx - 2 * P) - 4 * alpha) * n.u[4] + P * k.Dxy * n.w[4];
                 y1 += (P * (k.Dyy - 2 * P) - 4 * alpha) * n.w[4] + P * k.Dxy * n.u[4];
                 y2 += (-1 - 4 * beta) * n.g[4] + k.Dx * n.u[4] + k.Dy * n.w[4];
-                const size_t idx = (size_t)p * nj + q;
-                y0 = (double)b[off + idx] - y0;
-                y1 = (double)b[off + npts + idx] - y1;
-                y2 = (double)b[off + 2 * npts + idx] - y2;
+                y0 = (double)bc0 - y0;
+                y1 = (double)bc1 - y1;
+                y2 = (double)bc2 - y2;
             }
             double* rr = rs + (ap_slot(rc) * 3) * 128 + col;
             rr[0] = y0; rr[128] = y1; rr[256] = y2;
