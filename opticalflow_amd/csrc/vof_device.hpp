@@ -3630,16 +3630,24 @@ struct TailArgs {
 };
 
 // one colour of a block-GS sweep (UPDATE) or of the residual r = b - A x (!UPDATE) on an LDS-resident level
+// The stencil words of a thread's point of colour c (the thread has one point per colour on a tail level), requested one
+// colour ahead of their use (see k_tail_cycle)
+template <typename CT>
+__device__ __forceinline__ void tail_load(const TailLevel& lv, const typename CoefFmt<CT>::word_t* __restrict__ Cp, int c,
+                                          CoefSet<CT>& cf) {
+    const int t = threadIdx.x;
+    const int pp = t / lv.hj, qq = t - pp * lv.hj;
+    const int p = 2 * pp + (c >> 1), q = 2 * qq + (c & 1);
+    if (t >= lv.sub || p >= lv.ni || q >= lv.nj) return;
+    cf.load(Cp + (size_t)c * lv.sub + t, lv.plane);
+}
 template <typename CT, bool UPDATE>
-__device__ __forceinline__ void tail_colour(const TailLevel& lv, const typename CoefFmt<CT>::word_t* __restrict__ Cp,
-                                            double* lds, int ro, int c) {
+__device__ __forceinline__ void tail_colour(const TailLevel& lv, const CoefSet<CT>& cf, double* lds, int ro, int c) {
     const int t = threadIdx.x;
     const int pp = t / lv.hj, qq = t - pp * lv.hj;
     const int p = 2 * pp + (c >> 1), q = 2 * qq + (c & 1);
     if (t >= lv.sub || p >= lv.ni || q >= lv.nj) return;
     const int W2 = lv.nj + 2, fs = (lv.ni + 2) * W2, npts = lv.ni * lv.nj;
-    CoefSet<CT> cf;
-    cf.load(Cp + (size_t)c * lv.sub + t, lv.plane);
     double* xc = lds + lv.xo + (p + 1) * W2 + (q + 1);
     double y0 = 0, y1 = 0, y2 = 0;
 #pragma unroll
@@ -3710,13 +3718,37 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_cycle(TailArgs A, const V
                 for (int i = tid; i < n; i += TAIL_THREADS) lds[lv.xo + i] = 0.0;
                 __syncthreads();
             }
-            for (int sw = 0; sw < nu; ++sw)
-                for (int k = 0; k < 4; ++k) {
-                    tail_colour<CT, true>(lv, Cp, lds, A.ro, rev ? 3 - k : k);
-                    __syncthreads();
+            // two stencil sets: the next colour's words are requested before the barrier that ends the current colour
+            // (loaded at use, every colour of every sweep waited for its own stencil, with one workgroup of four waves
+            // per CU and nothing else to hide the latency behind)
+            // (the packed bfloat16 format only: two sets of the wider formats do not fit the registers)
+            constexpr bool AHEAD = std::is_same<CT, CoefB16>::value;
+            auto col = [&](int k) { return rev ? 3 - k : k; };
+            if constexpr (AHEAD) {
+                CoefSet<CT> sa, sb;
+                if (nu > 0) tail_load<CT>(lv, Cp, col(0), sa);
+                for (int sw = 0; sw < nu; ++sw) {
+                    tail_load<CT>(lv, Cp, col(1), sb); tail_colour<CT, true>(lv, sa, lds, A.ro, col(0)); __syncthreads();
+                    tail_load<CT>(lv, Cp, col(2), sa); tail_colour<CT, true>(lv, sb, lds, A.ro, col(1)); __syncthreads();
+                    tail_load<CT>(lv, Cp, col(3), sb); tail_colour<CT, true>(lv, sa, lds, A.ro, col(2)); __syncthreads();
+                    if (sw + 1 < nu) tail_load<CT>(lv, Cp, col(0), sa);
+                    tail_colour<CT, true>(lv, sb, lds, A.ro, col(3)); __syncthreads();
                 }
+            } else {
+                for (int sw = 0; sw < nu; ++sw)
+                    for (int k = 0; k < 4; ++k) {
+                        CoefSet<CT> sa;
+                        tail_load<CT>(lv, Cp, col(k), sa);
+                        tail_colour<CT, true>(lv, sa, lds, A.ro, col(k));
+                        __syncthreads();
+                    }
+            }
         } else if (code == T_RESTRICT) {   // b_{l+1} = R (b_l - A_l x_l)
-            for (int k = 0; k < 4; ++k) tail_colour<CT, false>(lv, Cp, lds, A.ro, k);
+            for (int k = 0; k < 4; ++k) {   // (no barrier in between: the compiler overlaps the four colours' loads itself)
+                CoefSet<CT> sa;
+                tail_load<CT>(lv, Cp, k, sa);
+                tail_colour<CT, false>(lv, sa, lds, A.ro, k);
+            }
             __syncthreads();
             const TailLevel& lc = A.L[l + 1];
             const int nf = lv.ni * lv.nj, nc = lc.ni * lc.nj;
