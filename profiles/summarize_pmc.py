@@ -70,7 +70,8 @@ def main():
             out[f"{nm}_L0_{size}x{size}x{frames}"] = {"hbm_bytes_per_launch": rd + wr, "fetch_x2_bytes": rd, "write_bytes": wr, "launches": n,
                                                      "kernel": sorted({sym for sym, _ in lst}), "grid": sorted({t[0] for _, t in lst})}
         # stored-level kernels share a symbol across levels: label the grid with the largest total traffic (level 1)
-        names = {"k_sweep<vof::SweepStored": ("gs", 1), "k_apply<": ("residual", 1)}
+        names = {"k_sweep<vof::SweepStored": ("gs", 1), "k_sweep_st<": ("gs", 1), "k_apply<": ("residual", 1),
+                 "k_resrestrict_u<": ("residual", 1)}
         for sym, lst in by_sym.items():
             for pat, (nm, level) in names.items():
                 if pat not in sym:
