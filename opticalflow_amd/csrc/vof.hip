@@ -303,9 +303,9 @@ ApplyGrid apply_grid(const vof_ctx* c, int np) {
 // number of per-pair partials is apply_grid().nblk.
 template <typename XT, typename BT, typename YT>
 void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np, const int* active,
-                  const double* dotvec = nullptr, int want_yy = 0) {
+                  const double* dotvec = nullptr, int want_yy = 0, YT* ycopy = nullptr) {
     Level& lv = c->L[0];
-    const double bytes = (8.0 + 3.0 * sizeof(XT) + (y ? 3.0 * sizeof(YT) : 0.0) + (mode ? 3.0 * sizeof(BT) : 0.0) +
+    const double bytes = (8.0 + 3.0 * sizeof(XT) + ((y ? 3.0 : 0.0) + (ycopy ? 3.0 : 0.0)) * sizeof(YT) + (mode ? 3.0 * sizeof(BT) : 0.0) +
                           (dotvec ? 24.0 : 0.0)) * lv.npts;
     Prof p(c, VOF_K_APPLY0, 0, bytes);
     if (c->stream_apply) {
@@ -314,13 +314,14 @@ void apply_fine_t(vof_ctx* c, const XT* x, const BT* b, YT* y, int mode, int np,
         if (mode)
             k_stream_apply0<1, XT, BT, YT><<<ag.grid, AP_THREADS, 0, c->stream>>>(
                 c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, ag.TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
-                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active, c->pp);
+                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active, c->pp, ycopy);
         else
             k_stream_apply0<0, XT, BT, YT><<<ag.grid, AP_THREADS, 0, c->stream>>>(
                 c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj, ag.TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
-                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active, c->pp);
+                c->prm.reference_quirks, x, b, y, dotvec, want_yy, part, ag.nblk, active, c->pp, ycopy);
         return;
     }
+    if (ycopy) { c->err = "internal: second output without the streaming operator kernel"; return; }
     dim3 g = grid2d(lv.ni, lv.nj, np);
     if (mode)
         k_apply0<1, XT, BT, YT><<<g, blk2d, 0, c->stream>>>(c->frames, frame_stride(c), c->Nj, lv.ni, lv.nj,
@@ -362,11 +363,14 @@ int krylov_apply(vof_ctx* c, const void* y, double* out, int np, const int* acti
 }
 // (out == nullptr with want_norm: only the norm is wanted - the streaming kernel then writes nothing; returns 0 if that is
 // not possible, and the caller falls back to a residual vector)
-int residual_d(vof_ctx* c, const double* x, const double* b, double* out, int np, const int* active, int want_norm = 0) {
+// out2 (streaming kernel only, see residual_copy_ok): a second copy of the residual
+inline bool residual_copy_ok(const vof_ctx* c) { return c->stream_apply && !c->L[0].C; }
+int residual_d(vof_ctx* c, const double* x, const double* b, double* out, int np, const int* active, int want_norm = 0,
+               double* out2 = nullptr) {
     if (!out && !(want_norm && c->stream_apply && !c->L[0].C)) return 0;
     if (c->L[0].C) { apply_stored_t<double>(c, 0, x, b, out, 1, np, active); return 0; }
     const bool fuse = c->stream_apply && want_norm;
-    apply_fine_t<double, double, double>(c, x, b, out, 1, np, active, nullptr, fuse ? 1 : 0);
+    apply_fine_t<double, double, double>(c, x, b, out, 1, np, active, nullptr, fuse ? 1 : 0, out2);
     return fuse ? apply_grid(c, np).nblk : 0;
 }
 
@@ -1107,30 +1111,34 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     const size_t len = 3 * f.npts;
     hipStream_t s = c->stream;
     // right-hand side and its norm
-    {   // b and the block partial sums of (b, b) in one pass
+    // initial guess (OF.py:799-802: constants, in pixels/frame), right-hand side, initial residual r0 and shadow residual r^ = r0
+    double sx = P.delta_t / P.delta_x;
+    const bool zero_guess = !c->guess_src && (P.initial_v_x == 0.0 && P.initial_v_y == 0.0 && P.initial_remodelling == 0.0);
+    double* rh = c->krh;   // r^: from the zero guess it IS b (read-only from here on) - no copy; a restart switches to the real buffer
+    {   // b and the block partial sums of (b, b) in one pass; from the zero guess r0 = b is written along
         Prof p(c, VOF_K_RHS, 0);
-        k_rhs_norm<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb, c->partials, c->pp);
+        k_rhs_norm<<<rgrid(c, np), RBLK, 0, s>>>(frames_dev, frame_stride(c), c->Nj, f.ni, f.nj, c->kb, zero_guess ? c->kr : nullptr,
+                                                c->partials, c->pp);
     }
     { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_BNORM><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
-    // initial guess (OF.py:799-802: constants, in pixels/frame) and initial residual
-    double sx = P.delta_t / P.delta_x;
-    bool zero_guess = (P.initial_v_x == 0.0 && P.initial_v_y == 0.0 && P.initial_remodelling == 0.0);
     int nb0 = c->nblk;   // per-pair partial sums of (r0, r0): from the zero guess they are those of (b, b), still in place
-    if (c->guess_src) {   // warm start from the solution of a neighbouring, already solved pair (cf. OF.py:803-806)
-        { Prof p(c, VOF_K_VECTOR, 0, 16.0 * len);
-          k_gather_guess<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->warm_x, c->guess_src, len, f.npts, P.initial_v_x * sx, P.initial_v_y * sx,
-                                                      P.initial_remodelling); }
-        nb0 = residual_d(c, c->kx, c->kb, c->kr, np, nullptr, 1);   // r0 = b - A x0 with the partial sums of (r0, r0)
-    } else if (zero_guess) {
+    if (zero_guess) {
         HIPCHK(hipMemsetAsync(c->kx, 0, (size_t)np * len * sizeof(double), s));
-        HIPCHK(hipMemcpyAsync(c->kr, c->kb, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
+        rh = c->kb;
     } else {
-        { Prof p(c, VOF_K_VECTOR, 0); k_fill<<<dim3(c->nblk, np), 256, 0, s>>>(c->kx, f.npts, P.initial_v_x * sx, P.initial_v_y * sx, P.initial_remodelling); }
-        nb0 = residual_d(c, c->kx, c->kb, c->kr, np, nullptr, 1);
+        if (c->guess_src) {   // warm start from the solution of a neighbouring, already solved pair (cf. OF.py:803-806)
+            Prof p(c, VOF_K_VECTOR, 0, 16.0 * len);
+            k_gather_guess<<<rgrid(c, np), RBLK, 0, s>>>(c->kx, c->warm_x, c->guess_src, len, f.npts, P.initial_v_x * sx, P.initial_v_y * sx,
+                                                        P.initial_remodelling);
+        } else {
+            Prof p(c, VOF_K_VECTOR, 0); k_fill<<<dim3(c->nblk, np), 256, 0, s>>>(c->kx, f.npts, P.initial_v_x * sx, P.initial_v_y * sx, P.initial_remodelling);
+        }
+        // r0 = b - A x0 with the partial sums of (r0, r0) and, where the streaming kernel runs, the copy r^ from the same pass
+        const bool two = residual_copy_ok(c);
+        nb0 = residual_d(c, c->kx, c->kb, c->kr, np, nullptr, 1, two ? c->krh : nullptr);
+        if (!two) HIPCHK(hipMemcpyAsync(c->krh, c->kr, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
-    HIPCHK(hipMemcpyAsync(c->krh, c->kr, (size_t)np * len * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemsetAsync(c->kp, 0, (size_t)np * len * sizeof(double), s));
-    HIPCHK(hipMemsetAsync(c->kv, 0, (size_t)np * len * sizeof(double), s));
+    // (p and v need no initialisation: the first iteration after a (re)start sets p = r without reading either)
     if (!nb0) {   // the operator kernel in use does not fuse the norm
         Prof p(c, VOF_K_REDUCE, 0); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kr, nullptr, nullptr, len, c->partials, nullptr);
         nb0 = c->nblk;
@@ -1156,15 +1164,16 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
         void* vrhs_s = c->vfloat ? (void*)c->b32 : (void*)c->kr;
         const double vsz = c->vfloat ? 4.0 : 8.0;
-        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 4 + (c->vfloat ? 4.0 * len : 0.0));   // p = r + beta (p - omega v)
-          VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
+        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * (it == 0 ? 2 : 4) + (c->vfloat ? 4.0 * len : 0.0));   // p = r + beta (p - omega v); first: p = r
+          VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr,
+                                                                   it == 0 ? 1 : 0))); }
         // y = M p and v = A y with (r^, v): the product comes out of the cycle's last smoothing pass when that path applies
-        c->trail_req = S0Trail{c->kv, c->krh, 0, c->partials};
+        c->trail_req = S0Trail{c->kv, rh, 0, c->partials};
         c->trail_set = true; c->trail_done = false;
         vcycle(c, &c->ky, vrhs_p, np, act);
         c->trail_set = false;
-        int nb1 = c->trail_done ? c->trail_nblk : krylov_apply(c, c->ky, c->kv, np, act, c->krh, 0);
-        if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->krh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
+        int nb1 = c->trail_done ? c->trail_nblk : krylov_apply(c, c->ky, c->kv, np, act, rh, 0);
+        if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(rh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, nb1, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 3 + (c->vfloat ? 4.0 * len : 0.0));   // s = r - alpha v, (s, s)
           VDISPATCH(c, (k_update_s<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kv, len, c->sc, c->partials, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
@@ -1181,7 +1190,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         if (!nb2) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); nb2 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, nb2, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 6 + 2.0 * vsz * len);   // x += alpha y + omega z; r = s - omega t; (r,r), (r^,r)
-          VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, (const VT*)c->kz, c->kr, c->kt, c->krh, len, c->sc, c->partials, act))); }
+          VDISPATCH(c, (k_update_xr<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, (const VT*)c->kz, c->kr, c->kt, rh, len, c->sc, c->partials, act))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_R><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
     }
     return 0;
@@ -1211,8 +1220,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
             if (nact == 0) break;
             if (int rc = independent_residual(true)) return rc;   // the restart needs the residual vector itself (rare)
             c->cur_units = nact;
-            { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 5);
-              k_restart_vectors<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->krh, c->kp, c->kv, c->kt, len, c->active); }
+            rh = c->krh;   // (the restarting pairs get their new r^ written; the others are done and no longer read theirs)
+            { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 3);
+              k_restart_vectors<<<rgrid(c, np), RBLK, 0, s>>>(c->kr, rh, c->kt, len, c->active); }
             if (int rc = bicg_loop(std::min(bicg_limit, 8))) return rc;
             if (int rc = independent_residual(false)) return rc;
         }

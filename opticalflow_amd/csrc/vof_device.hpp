@@ -1018,12 +1018,14 @@ __global__ __launch_bounds__(RBLK) void k_dot2(const double* __restrict__ a1, co
 
 // k_rhs with the block partial sums of (b, b): the right-hand side and its norm in one pass
 __global__ __launch_bounds__(RBLK) void k_rhs_norm(const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj,
-                                                   double* __restrict__ b, double* __restrict__ partials,
+                                                   double* __restrict__ b, double* __restrict__ r0, double* __restrict__ partials,
                                                    const PairParam* __restrict__ pp) {
+    // r0 (or nullptr): second copy of b - the initial residual of a solve that starts from zero
     const int pair = blockIdx.y;
     const size_t npts = (size_t)ni * nj;
     const double* I0 = frames + (size_t)(pp ? pp[pair].frame : pair) * frame_stride;
     double* bp = b + (size_t)pair * 3 * npts;
+    double* rp = r0 ? r0 + (size_t)pair * 3 * npts : nullptr;
     double s0 = 0.0;
     for (size_t t = (size_t)blockIdx.x * RBLK + threadIdx.x; t < npts; t += (size_t)gridDim.x * RBLK) {
         const int p = (int)(t / nj), q = (int)(t - (size_t)p * nj);
@@ -1035,13 +1037,16 @@ __global__ __launch_bounds__(RBLK) void k_rhs_norm(const double* __restrict__ fr
         const double dt = J[0] - I[0];                              // OF.py:821-823
         const double b0 = -P * dxt, b1 = -P * dyt, b2 = -dt;
         bp[t] = b0; bp[npts + t] = b1; bp[2 * npts + t] = b2;
+        if (rp) { rp[t] = b0; rp[npts + t] = b1; rp[2 * npts + t] = b2; }
         s0 += b0 * b0 + b1 * b1 + b2 * b2;
     }
     block_store_partials(s0, 0.0, 0.0, partials, 1, gridDim.x, pair, blockIdx.x);
 }
 
-// Epilogue in one pass: k_finalize (unpack + mirror boundary + unit scaling + speed, OF.py:1159-1166, 1189-1191) and the
-// functionals of k_functionals (OF.py:1167-1183) - the solution is read once.  Grid-stride over the full Ni x Nj output grid.
+// Epilogue in one pass: interior solution -> full-grid outputs with the reference's mirror fix-up (OF.py:1159-1166, rows then
+// columns: corners end as x(2,2)-type values), unit scaling and speed (OF.py:1189-1191), and the three functionals
+// (OF.py:1167-1183: L1 term, speed and remodelling regularisers, derivatives of the BC-fixed fields) - the solution is read
+// once.  Grid-stride over the full Ni x Nj output grid.
 __global__ __launch_bounds__(RBLK) void k_finalize_functionals(const double* __restrict__ frames, size_t frame_stride, int ni, int nj,
                                                                double alpha, double beta, int quirks, const double* __restrict__ x,
                                                                double vscale, double* __restrict__ vx, double* __restrict__ vy,
@@ -1098,7 +1103,8 @@ template <typename VT>
 __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const double* __restrict__ r,
                                                    const double* __restrict__ v, size_t len,
                                                    const PairScalars* __restrict__ sc,
-                                                   const int* __restrict__ active, VT* __restrict__ pcopy) {
+                                                   const int* __restrict__ active, VT* __restrict__ pcopy, int first) {
+    // first: the iteration that follows a (re)start, p = r (p and v are neither read nor need to be initialised)
     int pair = blockIdx.y;
     if (!active[pair]) return;
     double beta = sc[pair].beta, omega = sc[pair].omega;
@@ -1110,16 +1116,20 @@ __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const
         const double2* v2 = reinterpret_cast<const double2*>(v + off);
         V2* c2 = pcopy ? reinterpret_cast<V2*>(pcopy + off) : nullptr;
         for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len / 2; i += (size_t)gridDim.x * RBLK) {
-            double2 a = p2[i], rr = r2[i], vv = v2[i];
-            a.x = rr.x + beta * (a.x - omega * vv.x);
-            a.y = rr.y + beta * (a.y - omega * vv.y);
+            double2 a = r2[i];
+            if (!first) {
+                const double2 pp = p2[i], vv = v2[i];
+                a.x = a.x + beta * (pp.x - omega * vv.x);
+                a.y = a.y + beta * (pp.y - omega * vv.y);
+            }
             p2[i] = a;
             if (c2) { V2 t; t.x = (VT)a.x; t.y = (VT)a.y; c2[i] = t; }
         }
         return;
     }
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
-        double t = r[off + i] + beta * (p[off + i] - omega * v[off + i]);
+        double t = r[off + i];
+        if (!first) t = t + beta * (p[off + i] - omega * v[off + i]);
         p[off + i] = t;
         if (pcopy) pcopy[off + i] = (VT)t;
     }
@@ -1301,63 +1311,6 @@ __global__ void k_scalar(PairScalars* __restrict__ sc, const double* __restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Epilogue: interior solution -> full-grid outputs with the reference's mirror fix-up
-// (OF.py:1159-1166, rows then columns: corners end as x(2,2)-type values), unit scaling and speed
-// (OF.py:1189-1191).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_finalize(const double* __restrict__ x, int ni, int nj, double vscale,
-                                                 double* __restrict__ vx, double* __restrict__ vy,
-                                                 double* __restrict__ gm, double* __restrict__ speed,
-                                                 const PairParam* __restrict__ pp) {
-    int j = blockIdx.x * BX + threadIdx.x, i = blockIdx.y * BY + threadIdx.y, pair = blockIdx.z;
-    int Ni = ni + 2, Nj = nj + 2;
-    if (i >= Ni || j >= Nj) return;
-    size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
-    size_t idx = (size_t)fold(i - 1, ni) * nj + fold(j - 1, nj);
-    double u = x[off + idx] * vscale, w = x[off + npts + idx] * vscale, g = x[off + 2 * npts + idx];
-    size_t o = (size_t)(pp ? pp[pair].out : pair) * Ni * Nj + (size_t)i * Nj + j;
-    vx[o] = u;
-    vy[o] = w;
-    gm[o] = g;
-    if (speed) speed[o] = sqrt(u * u + w * w);
-}
-
-// Functionals of OF.py:1167-1183 on the BC-fixed fields (velocities in pixels/frame).
-__global__ __launch_bounds__(RBLK) void k_functionals(const double* __restrict__ frames, size_t frame_stride, int Nj,
-                                                      int ni, int nj, double alpha, double beta, int quirks,
-                                                      const double* __restrict__ x, double* __restrict__ partials,
-                                                      const PairParam* __restrict__ pp) {
-    int pair = blockIdx.y;
-    size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
-    const double* xu = x + off;
-    const double* xw = xu + npts;
-    const double* xg = xw + npts;
-    int fidx = pair;
-    if (pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
-    const double* I = frames + (size_t)fidx * frame_stride;
-    const double* J = I + frame_stride;
-    double sL = 0, sS = 0, sR = 0;
-    for (size_t t = (size_t)blockIdx.x * RBLK + threadIdx.x; t < npts; t += (size_t)gridDim.x * RBLK) {
-        int p = (int)(t / nj), q = (int)(t % nj);
-        PixCoef k = pix_coef(I, Nj, p, q, quirks);
-        double dt = J[(size_t)(p + 1) * Nj + q + 1] - k.P;
-        // BC-fixed field value at interior offset: plain fold (no corner factor)
-        int pm = fold(p - 1, ni), pp = fold(p + 1, ni), qm = fold(q - 1, nj), qp = fold(q + 1, nj);
-        size_t c = (size_t)p * nj + q;
-        size_t a_m = (size_t)pm * nj + q, a_p = (size_t)pp * nj + q;
-        size_t b_m = (size_t)p * nj + qm, b_p = (size_t)p * nj + qp;
-        double dux = (xu[a_p] - xu[a_m]) / 2, dwx = (xw[a_p] - xw[a_m]) / 2, dgx = (xg[a_p] - xg[a_m]) / 2;
-        double duy = quirks ? dux : (xu[b_p] - xu[b_m]) / 2;
-        double dwy = quirks ? dwx : (xw[b_p] - xw[b_m]) / 2;
-        double dgy = quirks ? dgx : (xg[b_p] - xg[b_m]) / 2;
-        double e = dt + xu[c] * k.Dx + xw[c] * k.Dy + k.P * dux + k.P * dwy - xg[c];
-        sL += e * e;
-        sS += dux * dux + duy * duy + dwx * dwx + dwy * dwy;
-        sR += dgx * dgx + dgy * dgy;
-    }
-    block_store_partials(sL, alpha * sS, beta * sR, partials, 3, gridDim.x, pair, blockIdx.x);
-}
 
 __global__ void k_sum3(const double* __restrict__ partials, int nblk, double* __restrict__ out3) {
     int pair = blockIdx.x;
@@ -1608,7 +1561,6 @@ __global__ void k_bicg_restart(PairScalars* __restrict__ sc, int* __restrict__ a
 }
 // r = r^ = t (the independent residual), p = v = 0 for the restarted pairs
 __global__ __launch_bounds__(RBLK) void k_restart_vectors(double* __restrict__ r, double* __restrict__ rh,
-                                                          double* __restrict__ p, double* __restrict__ v,
                                                           const double* __restrict__ t, size_t len,
                                                           const int* __restrict__ active) {
     int pair = blockIdx.y;
@@ -1616,7 +1568,7 @@ __global__ __launch_bounds__(RBLK) void k_restart_vectors(double* __restrict__ r
     size_t off = (size_t)pair * len;
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
         const double a = t[off + i];
-        r[off + i] = a; rh[off + i] = a; p[off + i] = 0.0; v[off + i] = 0.0;
+        r[off + i] = a; rh[off + i] = a;   // (p, v: the next iteration is a first one, see k_update_p)
     }
 }
 
@@ -3260,7 +3212,8 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
     const double* __restrict__ frames, size_t frame_stride, int Nj, int ni, int nj, int TI, double alpha, double beta,
     int quirks, const XT* __restrict__ x, const BT* __restrict__ b, YT* __restrict__ y,
     const double* __restrict__ dotvec, int want_yy, double* __restrict__ partials, int nblk,
-    const int* __restrict__ active, const PairParam* __restrict__ pp) {
+    const int* __restrict__ active, const PairParam* __restrict__ pp, YT* __restrict__ ycopy) {
+    // ycopy (or nullptr): a second copy of the result (the shadow residual of a warm-started solve)
     __shared__ XT xs[AP_RING * 3 * AP_W];
     __shared__ double im[AP_RING * AP_W];
     __shared__ double red[2][AP_THREADS / 64];
@@ -3364,6 +3317,11 @@ __global__ __launch_bounds__(AP_THREADS) void k_stream_apply0(
                 y[off + idx] = (YT)y0;
                 y[off + npts + idx] = (YT)y1;
                 y[off + 2 * npts + idx] = (YT)y2;
+            }
+            if (ycopy) {
+                ycopy[off + idx] = (YT)y0;
+                ycopy[off + npts + idx] = (YT)y1;
+                ycopy[off + 2 * npts + idx] = (YT)y2;
             }
             if (dotvec) {
                 s0 += y0 * dc0 + y1 * dc1 + y2 * dc2;
