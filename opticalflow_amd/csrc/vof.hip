@@ -2189,6 +2189,7 @@ int vof_debug_setup(vof_ctx* c, const double* movie_host, int n_pairs, const vof
     HIPCHK(hipMemcpyAsync(c->st_movie, movie_host, (size_t)(n_pairs + 1) * fs * sizeof(double), hipMemcpyHostToDevice,
                           c->stream));
     if (int rc = setup_batch(c, c->st_movie, n_pairs)) return rc;
+    c->vcoarse32 = p->vcycle_precision == 3;   // vof_debug_vcycle* run the cycle as a solve would (the per-level entry points: float64)
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -126,7 +126,7 @@ def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, be
 @pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES[1:3])
 def test_vcycle_matches_prototype(native, kind, shape, npairs, alpha, beta, seed):
     mv = make_case(kind, shape, npairs, seed)
-    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, nu_pre=2, nu_post=2,
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, vcycle_precision=0, nu_pre=2, nu_post=2,
                               nu_pre_coarse=2, nu_post_coarse=2, w_cycle_level=-1)
     with native.Solver(shape[0], shape[1], npairs) as s:
         s.debug_setup(mv, p)
@@ -263,9 +263,45 @@ def test_coarse_rhs_from_the_sweep_update(native, kind, shape, npairs, alpha, be
                 assert np.linalg.norm(got - want) < tol * scale, (lvl, x_old is None, np.linalg.norm(got - want) / scale)
 
 
+def test_coarse_correction_folded_into_the_stored_sweep(native, monkeypatch):
+    """VOF_FOLD_STORED=1: k_sweep_st interpolates the coarse-grid correction while it loads its rows (the stand-alone
+    prolongation kernel disappears) - same cycle, float64 and float32 vectors below level 0."""
+    mv = make_case("texture", (270, 530), 2, 5)
+    rng = np.random.default_rng(5)
+    for vp in (0, 3):
+        p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, vcycle_precision=vp)
+        res = []
+        for fold in ("0", "1"):
+            monkeypatch.setenv("VOF_FOLD_STORED", fold)
+            with native.Solver(270, 530, 2) as s:
+                s.debug_setup(mv, p)
+                if not res:
+                    r = rng.standard_normal((2, 3) + s.level_shape(0))
+                res.append(s.debug_vcycle(r))
+        assert relerr(res[1], res[0]) < 1e-12, vp
+
+
+@pytest.mark.parametrize("shape", [(130, 258), (131, 257)])
+def test_storage_modes_of_the_cycle_vectors_agree(native, shape):
+    """vcycle_precision 0 / 1 / 2 / 3: the cycle is the same operator up to float32 rounding of the vectors it stores as
+    float32 (mode 3: the levels below 0; odd row lengths fall back to float64 everywhere)."""
+    mv = make_case("texture", shape, 2, 7)
+    rng = np.random.default_rng(7)
+    out = {}
+    for vp in (0, 1, 2, 3):
+        p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, vcycle_precision=vp)
+        with native.Solver(shape[0], shape[1], 2) as s:
+            s.debug_setup(mv, p)
+            if not out:
+                r = rng.standard_normal((2, 3) + s.level_shape(0))
+            out[vp] = s.debug_vcycle(r)
+    for vp in (1, 2, 3):
+        assert relerr(out[vp], out[0]) < 2e-5, vp
+
+
 def test_vcycle_fused_equals_per_colour(native):
     mv = make_case("texture", (130, 130), 2, 3)
-    p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4)
+    p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, vcycle_precision=0)
     with native.Solver(130, 130, 2) as s:
         s.debug_setup(mv, p)
         r = s.debug_rhs()
@@ -329,7 +365,7 @@ def test_w_cycle_matches_prototype(native):
     the numpy prototype of the same recursion."""
     shape, npairs, alpha, beta = (130, 130), 1, 1.0, 1e4
     mv = make_case("texture", shape, npairs, 3)
-    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, nu_pre=2, nu_post=2,
+    p = native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=0, vcycle_precision=0, nu_pre=2, nu_post=2,
                               nu_pre_coarse=1, nu_post_coarse=1, w_cycle_level=1, w_cycle_visits=3)
     H = mg.Hierarchy(mv[0], alpha, beta)
 
