@@ -2294,15 +2294,22 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
         }
     };
     // off-diagonal stencil words of the stage's point of the step with e = eN -> set J
-    auto fetch_point = [&](auto fast_tag, auto jtag, const int eN) {
+    // (mask_tag: bit d set = the neighbour block d can meet a non-zero neighbour - all eight blocks, except in a sweep from
+    // zero, see below; word k of the packed format holds the coefficients 2k, 2k + 1 of the off-diagonal list)
+    auto fetch_point = [&](auto fast_tag, auto jtag, auto mask_tag, const int eN) {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int J = decltype(jtag)::value;
+        constexpr unsigned MASK = decltype(mask_tag)::value;
         const int rrn = eN + sro, pn = p0 + rrn;
-        if (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)) {
+        if (MASK != 0u && (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni))) {
             const word_t* base; unsigned idx;
             point_base(pn, base, idx, FAST);
 #pragma unroll
-            for (int k = 0; k < ND; ++k) cw[J][k] = (base + (size_t)k * L.plane)[idx];
+            for (int k = 0; k < ND; ++k) {
+                const int dd0 = (2 * k) / 9, dd1 = (2 * k + 1) / 9;
+                const int d0 = dd0 < 4 ? dd0 : dd0 + 1, d1 = dd1 < 4 ? dd1 : dd1 + 1;
+                if (((MASK >> d0) & 1u) || ((MASK >> d1) & 1u)) cw[J][k] = (base + (size_t)k * L.plane)[idx];
+            }
         }
     };
     // diagonal block and b of the stage's point of the step with e = eN
@@ -2321,9 +2328,10 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
 
     int slotA = sw_slot(-2);   // ring slot of relative row e + 2, advanced by 2 per step
     // JC: set of this step's point, 1 - JC: set requested for the next step
-    auto step = [&](auto fast_tag, auto jtag, const int e) {
+    auto step = [&](auto fast_tag, auto jtag, auto mask_tag, const int e) {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int JC = decltype(jtag)::value;
+        constexpr unsigned MASK = decltype(mask_tag)::value;
         const int slotB = slotA + 1;
         const bool do_load = FAST ? true : (e + 2 <= TI + 1);
         const XMap m1 = xmap(opaque_tid());
@@ -2362,7 +2370,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
             if (FAST) crv = ec[(size_t)cm.f * ncpts + (size_t)(kok ? knew : 0) * ncj + cm.g];
             else if (cm.cv && kok) crv = ec[(size_t)cm.f * ncpts + (size_t)knew * ncj + cm.g];
         }
-        fetch_point(fast_tag, std::integral_constant<int, 1 - JC>{}, e + 2);
+        fetch_point(fast_tag, std::integral_constant<int, 1 - JC>{}, mask_tag, e + 2);
         // (4) the stage of this lane: block Gauss-Seidel update of its point, neighbours read row by row
         {
             const int rr = e + sro, p = p0 + rr;
@@ -2379,6 +2387,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
 #pragma unroll
                     for (int bb = 0; bb < 3; ++bb) {
                         if (a == 1 && bb == 1) continue;
+                        if (!((MASK >> (a * 3 + bb)) & 1u)) continue;   // (a sweep from zero: this neighbour is still zero)
                         double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
                         const int d = a * 3 + bb, t0 = (d < 4 ? d : d - 1) * 9;
                         y0 += offd(c_, t0 + 0) * xu + offd(c_, t0 + 1) * xw + offd(c_, t0 + 2) * xg;
@@ -2444,25 +2453,39 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
     const int e_lo = max(10, 10 - p0);
     const int e_hi = min(TI - 2, ni - 4 - p0);
     auto pair_fast = [&](const int s) { return 2 * s >= e_lo && 2 * (s + 1) <= e_hi; };
-    int s = -2;
-    for (int part = 0; part < 2; ++part) {
-        while (s <= s_end && (part == 1 || !pair_fast(s))) {
-            step(std::false_type{}, std::integral_constant<int, 0>{}, 2 * s);
-            if (s + 1 <= s_end) step(std::false_type{}, std::integral_constant<int, 1>{}, 2 * (s + 1));
-            s += 2;
-        }
-        if (part == 0 && s <= s_end) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing requested by the predicated steps is still in flight
-            while (pair_fast(s)) {
-                step(std::true_type{}, std::integral_constant<int, 0>{}, 2 * s);
-                step(std::true_type{}, std::integral_constant<int, 1>{}, 2 * (s + 1));
+    auto run = [&](auto mask_tag) {
+        int s = -2;
+        for (int part = 0; part < 2; ++part) {
+            while (s <= s_end && (part == 1 || !pair_fast(s))) {
+                step(std::false_type{}, std::integral_constant<int, 0>{}, mask_tag, 2 * s);
+                if (s + 1 <= s_end) step(std::false_type{}, std::integral_constant<int, 1>{}, mask_tag, 2 * (s + 1));
                 s += 2;
             }
+            if (part == 0 && s <= s_end) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing requested by the predicated steps is still in flight
+                while (pair_fast(s)) {
+                    step(std::true_type{}, std::integral_constant<int, 0>{}, mask_tag, 2 * s);
+                    step(std::true_type{}, std::integral_constant<int, 1>{}, mask_tag, 2 * (s + 1));
+                    s += 2;
+                }
+            }
         }
+    };
+    // A sweep from zero in the forward colour order meets non-zero neighbours only where an earlier colour of the same sweep
+    // has been: colour 0 none (x = D^-1 b), colour 1 its left / right neighbours (blocks 3, 5), colour 2 the rows above and
+    // below (blocks 0-2, 6-8), colour 3 all eight.  The colour waves then request only the words of those blocks: 0 / 10 /
+    // 28 / 36 of the 36 off-diagonal words - the mirror image of k_resrestrict_u.  Skipping a block drops products with
+    // exact zeros: the result is the same, bit for bit.  (The wave of the halo points keeps all blocks: its lanes differ.)
+    if (!x_in && po == 0 && wave < 4) {
+        if (wave == 0) run(std::integral_constant<unsigned, 0x000u>{});
+        else if (wave == 1) run(std::integral_constant<unsigned, 0x028u>{});
+        else if (wave == 2) run(std::integral_constant<unsigned, 0x1C7u>{});
+        else run(std::integral_constant<unsigned, 0x1EFu>{});
+    } else {
+        run(std::integral_constant<unsigned, 0x1EFu>{});
     }
 }
 
-// ==========================================================================================
 // k_sweep0: the fused 4-colour sweep of level 0 (matrix-free), the north-star kernel.  Same schedule, strip geometry
 // (120 owned + 2 x 4 halo columns, 4 colour waves, 12-row ring, bands of TI rows) and results as
 // k_sweep<SweepFine, GeoA> above - bit for bit - but the row loop is rebuilt around its instruction budget (the PMC
