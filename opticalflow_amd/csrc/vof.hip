@@ -118,6 +118,7 @@ struct vof_ctx {
     bool fuse_prolong = true;   // level 0: coarse-grid correction interpolated inside the first post-sweep
     bool fuse_restrict = true;  // level 0: residual + restriction in one streaming pass
     bool sweep_st = true;       // stored levels, packed bfloat16 stencils: k_sweep_st (VOF_SWEEP_ST=0: the generic k_sweep)
+    bool skip_colour0 = true;   // ... revisits of a W-cycle: the first pre-smoothing sweep leaves colour 0 alone (VOF_SKIP_COLOUR0=0: full sweep)
     bool fold_stored = false;   // ... with the coarse-grid correction interpolated inside the first post-sweep (VOF_FOLD_STORED=1; measured:
                                 // the sweep gets slower by what the stand-alone prolongation kernel costs, so that one stays)
     bool fuse_resu = true;      // stored levels: coarse right-hand side from the last pre-smoothing sweep's update (k_resrestrict_u;
@@ -442,8 +443,9 @@ inline bool sweep_st_usable(const vof_ctx* c, int l) {
 template <typename VT>
 void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bool reverse, int np,
                    const int* active, const VT* ecoarse = nullptr, int nsweeps = 1, bool with_trail = false, bool ec32 = false,
-                   bool out64 = false) {
+                   bool out64 = false, bool skip0 = false) {
     // out64: x_out is written as float64 although VT is float (k_sweep_st only; the caller has checked that it applies)
+    // skip0: x_in comes straight from a reverse sweep with the same b - colour 0 needs no update (k_sweep_st; elsewhere ignored)
     // ec32: `ecoarse` really points at float32 data (float64 level 0 above float32 coarse levels; k_sweep0m only)
     Level& lv = c->L[l];
     int po = reverse ? 1 : 0;
@@ -524,11 +526,12 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             const uint32_t* Cw = (const uint32_t*)lv.C;
             if (ecoarse) {   // the sweep starts from x_in + P ecoarse (coarse rows through a 3-row LDS ring)
                 const size_t lds_e = lds + (size_t)9 * (W / 2 + 2) * sizeof(VT);
-                if (out64) k_sweep_st<CoefB16, VT, double, true><<<g, GeoB::THREADS, lds_e, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active, ecoarse, nci, ncj);
-                else k_sweep_st<CoefB16, VT, VT, true><<<g, GeoB::THREADS, lds_e, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj);
+                if (out64) k_sweep_st<CoefB16, VT, double, true><<<g, GeoB::THREADS, lds_e, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active, ecoarse, nci, ncj, 0);
+                else k_sweep_st<CoefB16, VT, VT, true><<<g, GeoB::THREADS, lds_e, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, 0);
             } else {
-                if (out64) k_sweep_st<CoefB16, VT, double><<<g, GeoB::THREADS, lds, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active, nullptr, 0, 0);
-                else k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, nullptr, 0, 0);
+                const int sk = (skip0 && x_in && !reverse) ? 1 : 0;
+                if (out64) k_sweep_st<CoefB16, VT, double><<<g, GeoB::THREADS, lds, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, (double*)x_out, b, active, nullptr, 0, 0, sk);
+                else k_sweep_st<CoefB16, VT><<<g, GeoB::THREADS, lds, c->stream>>>(Cw, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, nullptr, 0, 0, sk);
             }
             return;
         }
@@ -544,7 +547,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
 template <typename VT>
 VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool from_zero, bool reverse, int np,
                    const int* active, const VT* ecoarse = nullptr, bool allow_swap = false, bool final_smooth = false,
-                   bool ec32 = false, bool out64 = false) {
+                   bool ec32 = false, bool out64 = false, bool skip0 = false) {
     // Returns the buffer that holds the result: `x`, or `tmp` when allow_swap is set and the last out-of-place sweep
     // ended there (saves a device-to-device copy on the coarse levels).
     // ecoarse: coarse-grid correction still to be added (x += P ecoarse).  On the matrix-free level 0 it is folded
@@ -580,7 +583,7 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
         const bool trail = final_smooth && s == npass - 1 && c->trail_set && c->trail_enabled && l == 0 &&
                            std::is_same<VT, double>::value && sweep0m_usable(c) && src != nullptr;
         sweep_level_t<VT>(c, l, src, dst, b, reverse, np, active, s == 0 ? ecoarse : (const VT*)nullptr, ns, trail, ec32,
-                          out64 && s == npass - 1);
+                          out64 && s == npass - 1, skip0 && s == 0);
         left -= ns;
         src = dst;
         dst = (dst == x) ? tmp : x;
@@ -651,7 +654,9 @@ inline bool coarse32_ok(const vof_ctx* c, int nu_post) {
 // where the caller only reads it - `tmp`.  With prm.w_cycle_level == l the next coarser level is visited twice
 // (the second visit continues from the first one's result): a W-cycle restricted to one level.
 template <typename VT>
-VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* active, bool from_zero = true) {
+// after_post: x holds the result of a previous visit of this level with the same b, i.e. of its reverse post-smoothing sweep
+VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* active, bool from_zero = true,
+             bool after_post = false) {
     int last = (int)c->L.size() - 1;
     if (l == last) { coarse_solve_t<VT>(c, b, x, np, active); return x; }
     if (l == c->tail_first && l > 0 && tail_prepare(c)) { tail_cycle_t<VT>(c, x, b, np, active, from_zero); return x; }
@@ -664,7 +669,8 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
     // partner then still holds the input of the last sweep, which is all k_resrestrict_u needs besides the result.
     const bool resu = l > 0 && lv.C != nullptr && c->fused && c->fuse_resu && nu1 >= 1;
     if (l > 0 && c->fused) {
-        VT* xr = smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active, nullptr, /*allow_swap=*/true);
+        VT* xr = smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active, nullptr, /*allow_swap=*/true, false, false, false,
+                                    /*skip0=*/after_post && !from_zero && nu2 >= 1 && c->skip_colour0);
         if (xr != x) std::swap(x, tmp);
     } else {
         smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active);
@@ -712,7 +718,7 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
         const int visits = c->prm.w_cycle_visits > 0 ? c->prm.w_cycle_visits : 2;
         for (int v = 1; v < visits; ++v) {
             VT* other = (ec == cx) ? ct : cx;
-            ec = vcycle_t<VT>(c, l + 1, ec, other, (const VT*)nx.b, np, active, false);
+            ec = vcycle_t<VT>(c, l + 1, ec, other, (const VT*)nx.b, np, active, false, /*after_post=*/true);
         }
     }
     // (level 1 under a float64 level 0, vcycle_precision 3: the last post-smoothing sweep writes the result as float64)
@@ -1412,6 +1418,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_FUSE_RESU")) c->fuse_resu = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP_ST")) c->sweep_st = e[0] != '0';
     if (const char* e = getenv("VOF_FOLD_STORED")) c->fold_stored = e[0] != '0';
+    if (const char* e = getenv("VOF_SKIP_COLOUR0")) c->skip_colour0 = e[0] != '0';
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';

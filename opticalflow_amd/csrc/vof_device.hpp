@@ -2165,12 +2165,16 @@ __global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, i
 // EC: the sweep starts from x_in + P ecoarse (bilinear interpolation of the coarse-grid correction, as k_prolong_add computes it):
 // the coarse rows go through a 3-row LDS ring, one new row per step requested a step ahead, and are added to the fine rows on
 // their way into the x ring - the separate prolongation pass (read + write of x) disappears
+constexpr unsigned SWST_NO_UPDATE = 0x8000u;   // k_sweep_st: block mask value of a colour wave that leaves its colour alone
 template <typename CT, typename VT, typename OT = VT, bool EC = false>
 __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, int TI,
                                                                int po, int nx, int ny, int nz, const VT* __restrict__ x_in,
                                                                OT* __restrict__ x_out, const VT* __restrict__ b,
                                                                const int* __restrict__ active, const VT* __restrict__ ecoarse, int nci,
-                                                               int ncj) {
+                                                               int ncj, int skip0) {
+    // skip0: x_in comes straight from a sweep in REVERSE colour order with the same b (the post-smoothing of the previous
+    // visit of a W-cycle): colour 0 was updated last there and none of its neighbours has changed since - updating it again
+    // would reproduce its value, so this forward sweep leaves colour 0 alone (no stencil words, no arithmetic; same bits)
     typedef GeoB G;
     typedef typename CoefFmt<CT>::word_t word_t;
     constexpr int W = G::W, OUT = G::OUT, THREADS = G::THREADS, PLANES = CoefFmt<CT>::PLANES;
@@ -2264,6 +2268,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
     const int sro = (stage == 0) ? 0 : (stage == 1) ? -2 : (stage == 2) ? -5 : -7;
     const int rr_lo = (stage < 2) ? 0 : 1, rr_hi = (stage < 2) ? TI : TI - 1;
     const bool uni = wave < 4;                           // colour waves: the stage's row is wave-uniform
+    const bool upd_ok = !(skip0 && po == 0 && stage == 0);   // (halo lanes of colour 0 under skip0)
     const int sro_u = __builtin_amdgcn_readfirstlane(sro);
 
     // coefficients of the stage's point, this step's / the next step's: two sets of the off-diagonal words (planes 0 .. ND - 1),
@@ -2301,7 +2306,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
         constexpr int J = decltype(jtag)::value;
         constexpr unsigned MASK = decltype(mask_tag)::value;
         const int rrn = eN + sro, pn = p0 + rrn;
-        if (MASK != 0u && (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni))) {
+        if (MASK != 0u && MASK != SWST_NO_UPDATE && (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni))) {
             const word_t* base; unsigned idx;
             point_base(pn, base, idx, FAST);
 #pragma unroll
@@ -2313,10 +2318,11 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
         }
     };
     // diagonal block and b of the stage's point of the step with e = eN
-    auto fetch_diag = [&](auto fast_tag, const int eN) {
+    auto fetch_diag = [&](auto fast_tag, auto mask_tag, const int eN) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr bool NOUP = decltype(mask_tag)::value == SWST_NO_UPDATE;
         const int rrn = eN + sro, pn = p0 + rrn;
-        if (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni)) {
+        if (!NOUP && (FAST || (col_ok && rrn >= rr_lo && rrn <= rr_hi && pn >= 0 && pn < ni))) {
             const word_t* base; unsigned idx;
             point_base(pn, base, idx, FAST);
 #pragma unroll
@@ -2374,7 +2380,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
         // (4) the stage of this lane: block Gauss-Seidel update of its point, neighbours read row by row
         {
             const int rr = e + sro, p = p0 + rr;
-            if (col_ok && (FAST || (rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni))) {
+            if (MASK != SWST_NO_UPDATE && col_ok && upd_ok && (FAST || (rr >= rr_lo && rr <= rr_hi && p >= 0 && p < ni))) {
                 const int sU = sw_wrap(slotA + SW_RING + sro - 3), sC = sw_wrap(slotA + SW_RING + sro - 2),
                           sD = sw_wrap(slotA + SW_RING + sro - 1);
                 const int rowo[3] = {sU * 3 * W, sC * 3 * W, sD * 3 * W};
@@ -2407,7 +2413,7 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
                 row[0] = (VT)u; row[W] = (VT)w; row[2 * W] = (VT)gm;
             }
         }
-        fetch_diag(fast_tag, e + 2);   // the diagonal block of the next step's point (the registers are free now)
+        fetch_diag(fast_tag, mask_tag, e + 2);   // the diagonal block of the next step's point (the registers are free now)
         // (5) loaded rows -> LDS ring (the slots freed by (1), same thread <-> element mapping)
         const XMap m5 = xmap(opaque_tid());
         if (do_load && m5.on) {
@@ -2476,7 +2482,9 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
     // below (blocks 0-2, 6-8), colour 3 all eight.  The colour waves then request only the words of those blocks: 0 / 10 /
     // 28 / 36 of the 36 off-diagonal words - the mirror image of k_resrestrict_u.  Skipping a block drops products with
     // exact zeros: the result is the same, bit for bit.  (The wave of the halo points keeps all blocks: its lanes differ.)
-    if (!x_in && po == 0 && wave < 4) {
+    if (skip0 && po == 0 && wave == 0) {
+        run(std::integral_constant<unsigned, SWST_NO_UPDATE>{});
+    } else if (!x_in && po == 0 && wave < 4) {
         if (wave == 0) run(std::integral_constant<unsigned, 0x000u>{});
         else if (wave == 1) run(std::integral_constant<unsigned, 0x028u>{});
         else if (wave == 2) run(std::integral_constant<unsigned, 0x1C7u>{});
