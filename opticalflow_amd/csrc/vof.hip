@@ -1156,6 +1156,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     const int bicg_limit = P.krylov_method == 1 ? 0 : (P.krylov_method == 2 ? std::min(P.max_iterations, P.fallback_after) : P.max_iterations);
     int it_total = 0;   // BiCGStab iterations of this batch (all rounds)
     auto bicg_loop = [&](int limit) -> int {
+    bool ran_on_r = false;   // this round's first iteration ran the cycle on r instead of writing p = r
     for (int it = 0; it < limit; ++it, ++it_total) {
         HIPCHK(hipMemcpyAsync(c->h_active, c->active, np * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1170,9 +1171,17 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
         void* vrhs_s = c->vfloat ? (void*)c->b32 : (void*)c->kr;
         const double vsz = c->vfloat ? 4.0 : 8.0;
-        { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * (it == 0 ? 2 : 4) + (c->vfloat ? 4.0 * len : 0.0));   // p = r + beta (p - omega v); first: p = r
-          VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, c->kr, c->kv, len, c->sc, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr,
-                                                                   it == 0 ? 1 : 0))); }
+        // p = r + beta (p - omega v).  The iteration after a (re)start has p = r: the cycle then runs straight on r (unless it
+        // needs a float32 copy of its right-hand side) and no p is written - the next iteration finds that p in r^ = r0.
+        const bool on_r = it == 0 && !c->vfloat;
+        if (on_r) vrhs_p = (void*)c->kr;
+        else {
+            Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * (it == 0 ? 2 : 4) + (c->vfloat ? 4.0 * len : 0.0));
+            const double* p_old = (it == 1 && ran_on_r) ? rh : c->kp;
+            VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, p_old, c->kr, c->kv, len, c->sc, act,
+                                                                     c->vfloat ? (VT*)c->b32 : (VT*)nullptr, it == 0 ? 1 : 0)));
+        }
+        if (it == 0) ran_on_r = on_r;
         // y = M p and v = A y with (r^, v): the product comes out of the cycle's last smoothing pass when that path applies
         c->trail_req = S0Trail{c->kv, rh, 0, c->partials};
         c->trail_set = true; c->trail_done = false;

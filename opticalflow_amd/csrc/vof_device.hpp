@@ -1122,11 +1122,13 @@ __device__ __forceinline__ void stnt2(float2* p, float2 a) {
 
 // p = r + beta (p - omega v); optionally also a VT copy of p (the V-cycle's right-hand side)
 template <typename VT>
-__global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const double* __restrict__ r,
+__global__ __launch_bounds__(RBLK) void k_update_p(double* p, const double* p_old, const double* __restrict__ r,
                                                    const double* __restrict__ v, size_t len,
                                                    const PairScalars* __restrict__ sc,
                                                    const int* __restrict__ active, VT* __restrict__ pcopy, int first) {
-    // first: the iteration that follows a (re)start, p = r (p and v are neither read nor need to be initialised)
+    // first: the iteration that follows a (re)start, p = r (p and v are neither read nor need to be initialised).
+    // p_old: the previous search direction - p itself, or r^ = r0 in the second iteration when the first one ran the cycle
+    // straight on r (the solver then never wrote p = r0)
     int pair = blockIdx.y;
     if (!active[pair]) return;
     double beta = sc[pair].beta, omega = sc[pair].omega;
@@ -1134,13 +1136,14 @@ __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const
     if ((len & 1) == 0) {
         typedef typename Vec2<VT>::type V2;
         double2* p2 = reinterpret_cast<double2*>(p + off);
+        const double2* q2 = reinterpret_cast<const double2*>(p_old + off);
         const double2* r2 = reinterpret_cast<const double2*>(r + off);
         const double2* v2 = reinterpret_cast<const double2*>(v + off);
         V2* c2 = pcopy ? reinterpret_cast<V2*>(pcopy + off) : nullptr;
         for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len / 2; i += (size_t)gridDim.x * RBLK) {
             double2 a = ldnt2(r2 + i);
             if (!first) {
-                const double2 pp = ldnt2(p2 + i), vv = ldnt2(v2 + i);
+                const double2 pp = ldnt2(q2 + i), vv = ldnt2(v2 + i);
                 a.x = a.x + beta * (pp.x - omega * vv.x);
                 a.y = a.y + beta * (pp.y - omega * vv.y);
             }
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(RBLK) void k_update_p(double* __restrict__ p, const
     }
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
         double t = r[off + i];
-        if (!first) t = t + beta * (p[off + i] - omega * v[off + i]);
+        if (!first) t = t + beta * (p_old[off + i] - omega * v[off + i]);
         p[off + i] = t;
         if (pcopy) pcopy[off + i] = (VT)t;
     }
