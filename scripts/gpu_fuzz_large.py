@@ -11,7 +11,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
     n_i, n_j, T = int(rng.integers(400, 1150)), int(rng.integers(400, 1150)), int(rng.integers(2, 7))
     movie = texture_stack_numpy(max(n_i, n_j), T, seed=200 + case)[:, :n_i, :n_j]
     alpha, beta = float(10 ** rng.uniform(-0.2, 1.0)), float(10 ** rng.uniform(2.0, 4.0))
-    opts = dict(krylov_method=["auto", "gmres"][case % 2], vcycle_precision=["float64", "float32", "auto"][case % 3],
+    opts = dict(krylov_method=["auto", "gmres"][case % 2], vcycle_precision=["coarse_float32", "float64", "float32", "auto"][case % 4],
                 w_cycle_level=[None, -1, (1, 2), 2][case % 4], max_pairs_in_flight=[None, 2, 3][case % 3])
     t0 = time.time()
     res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, rtol=1e-7, return_stats=True, **opts)
