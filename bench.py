@@ -129,7 +129,7 @@ def main():
                          "129 per rank on several (configs[3]: 1024 pairs of 1024x1024 over 8 GPUs = 128 pairs per rank)")
     ap.add_argument("--pairs-in-flight", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-6)
-    ap.add_argument("--coarse-precision", default="bfloat16", choices=["float64", "float32", "bfloat16"])
+    ap.add_argument("--coarse-precision", default="float8", choices=["float64", "float32", "bfloat16", "float8"])
     ap.add_argument("--vcycle-precision", default="coarse_float32", choices=["float64", "float32", "auto", "coarse_float32"])
     ap.add_argument("--nu-pre", type=int, default=2)
     ap.add_argument("--nu-post", type=int, default=2)
@@ -212,7 +212,7 @@ def main():
     torch.cuda.synchronize()
 
     params = _native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=args.rtol,
-                                    coarse_precision={"float64": 0, "float32": 1, "bfloat16": 2}[args.coarse_precision],
+                                    coarse_precision={"float64": 0, "float32": 1, "bfloat16": 2, "float8": 3}[args.coarse_precision],
                                     vcycle_precision={"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3}[args.vcycle_precision],
                                     nu_pre=args.nu_pre, nu_post=args.nu_post, nu_pre_coarse=args.nu_pre_coarse,
                                     nu_post_coarse=args.nu_post_coarse)
@@ -222,7 +222,7 @@ def main():
         params.w_cycle_visits = args.w_cycle_visits
     if args.warm_start_stride is not None:
         params.warm_start_stride = args.warm_start_stride
-    coarse_bytes = {"float64": 8.0, "float32": 4.0, "bfloat16": 45 * 4 / 81.0}[args.coarse_precision]   # per coefficient
+    coarse_bytes = {"float64": 8.0, "float32": 4.0, "bfloat16": 45 * 4 / 81.0, "float8": 30 * 4 / 81.0}[args.coarse_precision]   # per coefficient
 
     def step(pv=None, mv=None):
         pv = pv or params
@@ -356,7 +356,7 @@ def main():
                                      "kernel_time_share_with_byte_count": counted_ms / total_ms}},
     }
     if world == 1 and not use_dist and not args.no_variants:
-        # informational, not the headline: the same step with other settings (headline = library defaults: bfloat16 /
+        # informational, not the headline: the same step with other settings (headline = library defaults: float8 /
         # float32 row-sum-preserving Galerkin stencils, float64 V-cycle vectors, two-phase warm start).  Arithmetic, Krylov vectors, stopping rule
         # and results are float64 in all of them.
         def timed(pv, mv=None):
@@ -378,6 +378,7 @@ def main():
             "constant_initial_fields_for_every_pair": timed(_native.default_params(vcycle_precision=vp, coarse_precision=cp, **cold)),
             "all_float64_storage": timed(_native.default_params(vcycle_precision=0, coarse_precision=0, **common)),
             "float32_stencils": timed(_native.default_params(vcycle_precision=vp, coarse_precision=1, **common)),
+            "bfloat16_stencils": timed(_native.default_params(vcycle_precision=vp, coarse_precision=2, **common)),
             "float64_vcycle_vectors_on_every_level": timed(_native.default_params(vcycle_precision=0, coarse_precision=cp, **common)),
             "float32_vcycle_vectors_on_every_level": timed(_native.default_params(vcycle_precision=2, coarse_precision=cp, **common)),
         }

@@ -45,9 +45,11 @@ typedef struct vof_params {
     int32_t nu_pre;            /* block-GS sweeps before the coarse-grid correction on level 0 (default 2) */
     int32_t nu_post;           /* ... and after (default 2) */
     int32_t reference_quirks;  /* 1 (default): OF.py:698-699 'dy' == 'dx'; OF.py:1205 speed_functional bug */
-    int32_t coarse_precision;  /* storage of the Galerkin stencils (preconditioner only): 2 (default) bfloat16 off-diagonal blocks +
-                                  float32 diagonal block that absorbs their rounding errors (block row sums kept; same iteration
-                                  counts as float32, 180 instead of 324 bytes per coarse point); 1: float32; 0: float64 */
+    int32_t coarse_precision;  /* storage of the Galerkin stencils (preconditioner only): 3 (default) 8-bit float off-diagonal
+                                  blocks (units of a power of two per block position) + float32 diagonal block that absorbs their
+                                  rounding errors (block row sums kept; 120 bytes per coarse point, +1 % iterations); 2: the same
+                                  with bfloat16 off-diagonal blocks (180 bytes, iteration counts of float32); 1: float32 (324
+                                  bytes); 0: float64 */
     int32_t vcycle_precision;  /* storage of the V-cycle vectors: 0 float64; 1 float32; 2 auto = float32 for the first 8
                                   iterations, float64 afterwards; 3 (default) = float64 on level 0, float32 on the levels below
                                   for the first 8 iterations (arithmetic, Krylov vectors and stopping rule always FP64) */

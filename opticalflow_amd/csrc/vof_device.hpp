@@ -82,12 +82,42 @@ struct CLay {
 //                    iteration count of every regime unchanged.  180 instead of 324 bytes per point.
 // ------------------------------------------------------------------------------------------
 struct CoefB16 {};
-template <typename CT> struct CoefFmt { typedef CT word_t; static constexpr int PLANES = 81; };
-template <> struct CoefFmt<CoefB16> { typedef uint32_t word_t; static constexpr int PLANES = 45; };
+//   CoefF8         : 30 planes of 32-bit words.  The 72 off-diagonal coefficients are 8-bit floats (4 exponent, 3 mantissa
+//                    bits: the device's v_cvt_pk_fp8_f32 / v_cvt_f32_fp8 pair encodes and decodes them), four per word
+//                    (coefficient j of the off-diagonal list in byte j & 3 of word j >> 2), each in units of a power of two
+//                    PER POSITION (r, c) OF THE 3x3 BLOCKS (the largest magnitude of that position over the eight neighbour
+//                    blocks lands in [64, 128): the couplings of one equation differ by the ratio beta / alpha, more than the
+//                    format's range - with one unit per equation the iteration counts rose by 4 %); the diagonal block stays
+//                    float32 in planes 18-26 and absorbs the rounding errors as in CoefB16; plane 27 + r holds the biased
+//                    float32 exponents of the units of row r (byte c).  120 instead of 180 bytes per point; measured with the
+//                    bfloat16 words rounded to 3 mantissa bits (-DVOF_EXP_MANT_BITS=3): +1 % iterations.
+struct CoefF8 {};
+template <typename CT> struct CoefFmt { typedef CT word_t; static constexpr int PLANES = 81; static constexpr int ND = 72; };
+template <> struct CoefFmt<CoefB16> { typedef uint32_t word_t; static constexpr int PLANES = 45; static constexpr int ND = 36; };
+template <> struct CoefFmt<CoefF8> { typedef uint32_t word_t; static constexpr int PLANES = 30; static constexpr int ND = 18; };
+// packed formats: ND words of off-diagonal coefficients, then the float32 diagonal block (then the row units of CoefF8)
+template <typename CT> struct CoefPacked { static constexpr bool value = std::is_same<CT, CoefB16>::value || std::is_same<CT, CoefF8>::value; };
+
+__device__ __forceinline__ float f8_decode(uint32_t w, int sel) {   // byte `sel` of w (the selector is an immediate of the instruction)
+    switch (sel & 3) {
+        case 0: return __builtin_amdgcn_cvt_f32_fp8((int)w, 0);
+        case 1: return __builtin_amdgcn_cvt_f32_fp8((int)w, 1);
+        case 2: return __builtin_amdgcn_cvt_f32_fp8((int)w, 2);
+        default: return __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+    }
+}
+__device__ __forceinline__ float f8_unit(uint32_t ew, int r) {   // unit of equation r from the exponent word of a CoefF8 point
+    return __uint_as_float(((ew >> (8 * r)) & 0xFFu) << 23);
+}
 
 __device__ __forceinline__ uint32_t bf16_round(float f) {   // bfloat16 bits (in the low half) of f, round to nearest even
     uint32_t u = __float_as_uint(f);
+#ifdef VOF_EXP_MANT_BITS   // probe: what a narrower off-diagonal format would cost in iterations (mantissa bits kept, of bfloat16's 7)
+    constexpr int DROP = 23 - VOF_EXP_MANT_BITS;
+    return ((u + ((1u << (DROP - 1)) - 1u) + ((u >> DROP) & 1u)) >> DROP) << (DROP - 16);
+#else
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+#endif
 }
 
 // The coefficients of one point in registers.
@@ -117,6 +147,11 @@ template <typename CT> struct CoefSet {
             const int j = (d < 4 ? d : d - 1) * 9 + e;
             const uint32_t v = w[j >> 1];
             return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+        } else if constexpr (std::is_same<CT, CoefF8>::value) {
+            const int d = i / 9, e = i - 9 * d;
+            if (d == 4) return (double)__uint_as_float(w[18 + e]);
+            const int j = (d < 4 ? d : d - 1) * 9 + e;
+            return (double)(f8_decode(w[j >> 2], j & 3) * f8_unit(w[27 + e / 3], e % 3));
         } else {
             return (double)w[i];
         }
@@ -131,6 +166,12 @@ __device__ __forceinline__ double coef_at(const typename CoefFmt<CT>::word_t* __
         const int j = (d < 4 ? d : d - 1) * 9 + e;
         const uint32_t v = Cp[(size_t)(j >> 1) * plane + idx];
         return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+    } else if constexpr (std::is_same<CT, CoefF8>::value) {
+        const int d = i / 9, e = i - 9 * d;
+        if (d == 4) return (double)__uint_as_float(Cp[(size_t)(18 + e) * plane + idx]);
+        const int j = (d < 4 ? d : d - 1) * 9 + e;
+        const uint32_t v = Cp[(size_t)(j >> 2) * plane + idx] >> (8 * (j & 3));
+        return (double)(__builtin_amdgcn_cvt_f32_fp8((int)v, 0) * f8_unit(Cp[(size_t)(27 + e / 3) * plane + idx], e % 3));
     } else {
         return (double)Cp[(size_t)i * plane + idx];
     }
@@ -602,6 +643,21 @@ __device__ __forceinline__ void coef_load_blocks(CoefSet<CT>& cs, const typename
             const int d0 = dd0 < 4 ? dd0 : dd0 + 1, d1 = dd1 < 4 ? dd1 : dd1 + 1;
             if (((DMASK >> d0) & 1u) || ((DMASK >> d1) & 1u)) cs.w[k] = ok ? (rowbase + (size_t)k * plane)[col] : 0u;
         }
+    } else if constexpr (std::is_same<CT, CoefF8>::value) {
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {   // word k holds the off-diagonal coefficients 4k .. 4k + 3
+            bool need = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int dd = (4 * k + u) / 9, d = dd < 4 ? dd : dd + 1;
+                need = need || ((DMASK >> d) & 1u);
+            }
+            if (need) cs.w[k] = ok ? (rowbase + (size_t)k * plane)[col] : 0u;
+        }
+        if (DMASK & 0x1EFu) {   // the units
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cs.w[27 + r] = ok ? (rowbase + (size_t)(27 + r) * plane)[col] : 0u;
+        }
     } else {
 #pragma unroll
         for (int d = 0; d < 9; ++d)
@@ -617,7 +673,7 @@ __device__ __forceinline__ void coef_load_blocks(CoefSet<CT>& cs, const typename
 // Register budget (launch bound, waves per SIMD): 4 for the packed bfloat16 stencils (104-113 registers; 3 with float64
 // vectors and x_old, which would spill a few), 2 for the float32 / float64 formats (72 coefficient words for colour 0).
 template <typename CT, typename VT, bool HAS_OLD> struct ResuBudget {
-    static constexpr int kMinWaves = !std::is_same<CT, CoefB16>::value ? 2 : ((HAS_OLD && sizeof(VT) == 8) ? 3 : 4);
+    static constexpr int kMinWaves = !CoefPacked<CT>::value ? 2 : ((HAS_OLD && sizeof(VT) == 8) ? 3 : 4);
 };
 #ifdef RESU_NO_FENCE
 #define RESU_PHASE_FENCE() do {} while (0)
@@ -859,6 +915,51 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
         for (int j = 0; j < 36; ++j) out[(size_t)j * nc] = h[2 * j] | (h[2 * j + 1] << 16);
 #pragma unroll
         for (int t = 0; t < 9; ++t) out[(size_t)(36 + t) * nc] = __float_as_uint(diag[t]);
+    } else if constexpr (std::is_same<CTC, CoefF8>::value) {
+        // off-diagonal blocks -> 8-bit floats in units of a power of two per block position; rounding errors to the diagonal block
+        float diag[9], amax[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { diag[t] = 0.25f * acc[4][t]; amax[t] = 0.f; }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+            if (d == 4) continue;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) amax[t] = fmaxf(amax[t], fabsf(0.25f * acc[d][t]));
+        }
+        uint32_t ew[3] = {0u, 0u, 0u};
+        float unit[9], inv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // biased exponent of the unit: that of the maximum minus 6 (maximum / unit in [64, 128)), kept a normal number
+            int eb = (int)((__float_as_uint(amax[t]) >> 23) & 0xFFu) - 6;
+            eb = eb < 1 ? 1 : (eb > 253 ? 253 : eb);
+            ew[t / 3] |= (uint32_t)eb << (8 * (t % 3));
+            unit[t] = __uint_as_float((uint32_t)eb << 23);
+            inv[t] = __uint_as_float((uint32_t)(254 - eb) << 23);
+        }
+        float sv[72];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+            if (d == 4) continue;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sv[(d < 4 ? d : d - 1) * 9 + t] = 0.25f * acc[d][t] * inv[t];
+        }
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * k], sv[4 * k + 1], w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4 * k + 2], sv[4 * k + 3], w, true);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * k + u, t = j % 9;
+                diag[t] += (sv[j] - f8_decode((uint32_t)w, u)) * unit[t];
+            }
+            out[(size_t)k * nc] = (uint32_t)w;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[(size_t)(18 + t) * nc] = __float_as_uint(diag[t]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out[(size_t)(27 + r) * nc] = ew[r];
     } else {
 #pragma unroll
         for (int d = 0; d < 9; ++d)
@@ -2276,8 +2377,10 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
 
     // coefficients of the stage's point, this step's / the next step's: two sets of the off-diagonal words (planes 0 .. ND - 1),
     // one set of the diagonal block (planes ND ..), which is requested when the update that used the previous one is done
-    constexpr int ND = std::is_same<CT, CoefB16>::value ? 36 : 36;   // (packed bfloat16: 36 words + 9 floats)
-    static_assert(std::is_same<CT, CoefB16>::value, "k_sweep_st is written for the packed bfloat16 stencils");
+    constexpr int ND = CoefFmt<CT>::ND;   // (bfloat16: 36 words + 9 floats; 8-bit floats: 18 words + 9 floats + the row units)
+    constexpr bool F8 = std::is_same<CT, CoefF8>::value;
+    constexpr int PW = F8 ? 4 : 2;         // off-diagonal coefficients per word
+    static_assert(CoefPacked<CT>::value, "k_sweep_st is written for the packed stencil formats");
     word_t cw[2][ND], dg[PLANES - ND];
     VT bq[3];                                            // b of the stage's point: requested with the diagonal block
 #pragma unroll
@@ -2285,9 +2388,13 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
 #pragma unroll
     for (int k = 0; k < PLANES - ND; ++k) dg[k] = 0;
     bq[0] = bq[1] = bq[2] = (VT)0;
-    auto offd = [](const word_t* w, int j) {   // off-diagonal coefficient j (0..71) of a set
-        const uint32_t v = w[j >> 1];
-        return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+    auto offd = [](const word_t* w, int j) {   // off-diagonal coefficient j (0..71) of a set (CoefF8: in the units of its row)
+        if constexpr (F8) {
+            return (double)f8_decode(w[j >> 2], j & 3);
+        } else {
+            const uint32_t v = w[j >> 1];
+            return (double)__uint_as_float((j & 1) ? (v & 0xFFFF0000u) : (v << 16));
+        }
     };
 
     // base pointer (wave-uniform part) and lane index of the stencil words of the stage's point in row pn
@@ -2314,9 +2421,13 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
             point_base(pn, base, idx, FAST);
 #pragma unroll
             for (int k = 0; k < ND; ++k) {
-                const int dd0 = (2 * k) / 9, dd1 = (2 * k + 1) / 9;
-                const int d0 = dd0 < 4 ? dd0 : dd0 + 1, d1 = dd1 < 4 ? dd1 : dd1 + 1;
-                if (((MASK >> d0) & 1u) || ((MASK >> d1) & 1u)) cw[J][k] = (base + (size_t)k * L.plane)[idx];
+                bool need = false;
+#pragma unroll
+                for (int u = 0; u < PW; ++u) {
+                    const int dd = (PW * k + u) / 9, d = dd < 4 ? dd : dd + 1;
+                    need = need || ((MASK >> d) & 1u);
+                }
+                if (need) cw[J][k] = (base + (size_t)k * L.plane)[idx];
             }
         }
     };
@@ -2390,6 +2501,11 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
                 const int colo[3] = {uL, cC, uR};
                 const word_t* c_ = cw[JC];
                 double y0 = 0, y1 = 0, y2 = 0;
+                double yp[F8 ? 9 : 1];      // CoefF8: one sum per block position, in the units of that position
+                if constexpr (F8) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) yp[t] = 0;
+                }
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const VT* row = xs + rowo[a];
@@ -2399,9 +2515,18 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
                         if (!((MASK >> (a * 3 + bb)) & 1u)) continue;   // (a sweep from zero: this neighbour is still zero)
                         double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
                         const int d = a * 3 + bb, t0 = (d < 4 ? d : d - 1) * 9;
-                        y0 += offd(c_, t0 + 0) * xu + offd(c_, t0 + 1) * xw + offd(c_, t0 + 2) * xg;
-                        y1 += offd(c_, t0 + 3) * xu + offd(c_, t0 + 4) * xw + offd(c_, t0 + 5) * xg;
-                        y2 += offd(c_, t0 + 6) * xu + offd(c_, t0 + 7) * xw + offd(c_, t0 + 8) * xg;
+                        if constexpr (F8) {
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) {
+                                yp[3 * r + 0] += offd(c_, t0 + 3 * r + 0) * xu;
+                                yp[3 * r + 1] += offd(c_, t0 + 3 * r + 1) * xw;
+                                yp[3 * r + 2] += offd(c_, t0 + 3 * r + 2) * xg;
+                            }
+                        } else {
+                            y0 += offd(c_, t0 + 0) * xu + offd(c_, t0 + 1) * xw + offd(c_, t0 + 2) * xg;
+                            y1 += offd(c_, t0 + 3) * xu + offd(c_, t0 + 4) * xw + offd(c_, t0 + 5) * xg;
+                            y2 += offd(c_, t0 + 6) * xu + offd(c_, t0 + 7) * xw + offd(c_, t0 + 8) * xg;
+                        }
                     }
 #ifndef SWST_NO_ROW_FENCE
                     asm volatile("" ::: "memory");   // keep the LDS reads of the next row behind this row's arithmetic
@@ -2410,6 +2535,11 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
                 double Dm[9];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) Dm[t] = (double)__uint_as_float(dg[t]);
+                if constexpr (F8) {
+                    y0 = yp[0] * (double)f8_unit(dg[9], 0) + yp[1] * (double)f8_unit(dg[9], 1) + yp[2] * (double)f8_unit(dg[9], 2);
+                    y1 = yp[3] * (double)f8_unit(dg[10], 0) + yp[4] * (double)f8_unit(dg[10], 1) + yp[5] * (double)f8_unit(dg[10], 2);
+                    y2 = yp[6] * (double)f8_unit(dg[11], 0) + yp[7] * (double)f8_unit(dg[11], 1) + yp[8] * (double)f8_unit(dg[11], 2);
+                }
                 double u, w, gm;
                 solve3(Dm, (double)bq[0] - y0, (double)bq[1] - y1, (double)bq[2] - y2, u, w, gm);
                 VT* row = xs + rowo[1] + cC;
@@ -3736,7 +3866,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_cycle(TailArgs A, const V
             // (loaded at use, every colour of every sweep waited for its own stencil, with one workgroup of four waves
             // per CU and nothing else to hide the latency behind)
             // (the packed bfloat16 format only: two sets of the wider formats do not fit the registers)
-            constexpr bool AHEAD = std::is_same<CT, CoefB16>::value;
+            constexpr bool AHEAD = CoefPacked<CT>::value;
             auto col = [&](int k) { return rev ? 3 - k : k; };
             if constexpr (AHEAD) {
                 CoefSet<CT> sa, sb;

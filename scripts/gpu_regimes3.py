@@ -13,7 +13,8 @@ for n in (66, 130, 258, 514, 1026):
         if n > 600 and name in ("T", "W"):
             continue
         mv = texture_stack_numpy(n, 4, 5) * scale
-        r = of.variational_optical_flow(mv, speed_alpha=al, remodelling_alpha=be, return_stats=True, max_iterations=200)
+        r = of.variational_optical_flow(mv, speed_alpha=al, remodelling_alpha=be, return_stats=True, max_iterations=200,
+                                        coarse_precision=os.environ.get("COARSE", "bfloat16"))
         st = r["stats"]
         row.append(f"{name}:{st['iterations'].sum():3d}/{st['iterations'].max():3d}{'' if st['converged'].all() else '!'}")
     print(f"{tag:8s} n={n:4d} ", "  ".join(row), flush=True)

@@ -40,7 +40,7 @@ def test_version_and_default_params(lib):
     # the reference's solver settings: OF.py:718-719, 1120
     assert (p.speed_alpha, p.remodelling_alpha, p.rtol, p.max_iterations) == (1.0, 1000.0, 1e-6, 1000)
     assert (p.nu_pre, p.nu_post, p.nu_pre_coarse, p.nu_post_coarse, p.w_cycle_level, p.w_cycle_visits) == (2, 2, 1, 1, 1, 3)
-    assert (p.reference_quirks, p.coarse_precision, p.vcycle_precision) == (1, 2, 3)
+    assert (p.reference_quirks, p.coarse_precision, p.vcycle_precision) == (1, 3, 3)
     assert C.sizeof(_native.VofParams) == 2 * 4 + 8 * 8 + 16 * 4 == lib.vof_params_size()
     assert C.sizeof(_native.VofPairStats) == 40
     with pytest.raises(TypeError):

@@ -209,12 +209,12 @@ def test_coarse_stencil_precision_does_not_change_the_answer(of):
     movie = orc.make_texture_stack(96, 3, seed=4)
     a = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, coarse_precision="float64",
                                     return_stats=True)
-    for fmt in ("float32", "bfloat16"):
+    for fmt in ("float32", "bfloat16", "float8"):
         b = of.variational_optical_flow(movie, remodelling_alpha=1e4, rtol=1e-10, coarse_precision=fmt, return_stats=True)
         assert b["stats"]["converged"].all()
         for k in ("v_x", "v_y", "remodelling"):
             assert relerr(b[k], a[k]) < 1e-8, (fmt, k)
-        assert np.abs(b["stats"]["iterations"].astype(int) - a["stats"]["iterations"]).max() <= 1, fmt
+        assert np.abs(b["stats"]["iterations"].astype(int) - a["stats"]["iterations"]).max() <= (2 if fmt == "float8" else 1), fmt
 
 
 def test_medium_size_properties_512(of):
@@ -399,7 +399,7 @@ def test_seeded_random_configurations_against_oracle(of, case):
     kw = dict(speed_alpha=alpha, remodelling_alpha=beta, delta_x=float(rng.uniform(0.2, 2.0)), delta_t=float(rng.uniform(0.5, 2.0)),
               initial_v_x=float(rng.uniform(-0.5, 0.5)), initial_v_y=float(rng.uniform(-0.5, 0.5)),
               initial_remodelling=float(rng.uniform(-0.1, 0.1)), reference_quirks=bool(case % 5 != 0))
-    opts = dict(krylov_method=["auto", "bicgstab", "gmres"][case % 3], coarse_precision=["bfloat16", "float32", "float64", "bfloat16"][case % 4],
+    opts = dict(krylov_method=["auto", "bicgstab", "gmres"][case % 3], coarse_precision=["bfloat16", "float32", "float64", "float8"][case % 4],
                 vcycle_precision=["float64", "float32", "auto", "coarse_float32"][(case // 2) % 4], w_cycle_level=[None, -1, 0, (1, 2)][case % 4],
                 multigrid_sweeps=[None, (1, 1), (2, 1, 2, 2), (3, 3)][(case // 3) % 4], max_pairs_in_flight=[None, 1, 2][case % 3])
     ref = orc.variational_optical_flow(movie, **kw)
@@ -431,7 +431,7 @@ def test_seeded_random_medium_sizes_by_independent_residual(of, case):
     movie = orc.make_texture_stack(max(n_i, n_j), T, seed=100 + case)[:, :n_i, :n_j]
     alpha, beta = float(10 ** rng.uniform(-0.3, 1.5)), float(10 ** rng.uniform(1.0, 4.0))
     quirks = bool(case % 4 != 0)
-    opts = dict(krylov_method=["auto", "gmres"][case % 2], coarse_precision=["bfloat16", "float32", "float64"][(case // 2) % 3],
+    opts = dict(krylov_method=["auto", "gmres"][case % 2], coarse_precision=["bfloat16", "float32", "float64", "float8"][(case // 2) % 4],
                 vcycle_precision=["float64", "float32", "auto", "coarse_float32"][case % 4], w_cycle_level=[None, -1, (1, 2), 2][case % 4],
                 max_pairs_in_flight=[None, 2][case % 2])
     res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, reference_quirks=quirks, rtol=1e-8,
