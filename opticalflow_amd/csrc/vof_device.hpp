@@ -2270,8 +2270,14 @@ __global__ __launch_bounds__(G::THREADS, Pol::kMinWaves) void k_sweep(Pol pol, i
 // the coarse rows go through a 3-row LDS ring, one new row per step requested a step ahead, and are added to the fine rows on
 // their way into the x ring - the separate prolongation pass (read + write of x) disappears
 constexpr unsigned SWST_NO_UPDATE = 0x8000u;   // k_sweep_st: block mask value of a colour wave that leaves its colour alone
+// waves per SIMD the register allocation aims at: 3 (170 registers; two workgroups of five waves per CU) with the two sets of 36
+// bfloat16 words, 4 (128 registers; three workgroups) with the two sets of 18 words of the 8-bit format
+#ifndef SWST_F8_WAVES
+#define SWST_F8_WAVES 4
+#endif
+template <typename CT> struct SweepStBudget { static constexpr int kMinWaves = std::is_same<CT, CoefF8>::value ? SWST_F8_WAVES : 3; };
 template <typename CT, typename VT, typename OT = VT, bool EC = false>
-__global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, int TI,
+__global__ __launch_bounds__(GeoB::THREADS, SweepStBudget<CT>::kMinWaves) void k_sweep_st(const typename CoefFmt<CT>::word_t* __restrict__ C, int ni, int nj, int TI,
                                                                int po, int nx, int ny, int nz, const VT* __restrict__ x_in,
                                                                OT* __restrict__ x_out, const VT* __restrict__ b,
                                                                const int* __restrict__ active, const VT* __restrict__ ecoarse, int nci,
@@ -2501,7 +2507,10 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
                 const int colo[3] = {uL, cC, uR};
                 const word_t* c_ = cw[JC];
                 double y0 = 0, y1 = 0, y2 = 0;
-                double yp[F8 ? 9 : 1];      // CoefF8: one sum per block position, in the units of that position
+                // CoefF8: one sum per block position, in the units of that position (float32 sums for float32 vectors: measured, no
+                // faster and no fewer registers)
+                typedef double AT;
+                AT yp[F8 ? 9 : 1];
                 if constexpr (F8) {
 #pragma unroll
                     for (int t = 0; t < 9; ++t) yp[t] = 0;
@@ -2516,11 +2525,12 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
                         double xu = (double)row[colo[bb]], xw = (double)row[W + colo[bb]], xg = (double)row[2 * W + colo[bb]];
                         const int d = a * 3 + bb, t0 = (d < 4 ? d : d - 1) * 9;
                         if constexpr (F8) {
+                            const AT au = (AT)row[colo[bb]], aw = (AT)row[W + colo[bb]], ag = (AT)row[2 * W + colo[bb]];
 #pragma unroll
                             for (int r = 0; r < 3; ++r) {
-                                yp[3 * r + 0] += offd(c_, t0 + 3 * r + 0) * xu;
-                                yp[3 * r + 1] += offd(c_, t0 + 3 * r + 1) * xw;
-                                yp[3 * r + 2] += offd(c_, t0 + 3 * r + 2) * xg;
+                                yp[3 * r + 0] += (AT)f8_decode(c_[(t0 + 3 * r + 0) >> 2], (t0 + 3 * r + 0) & 3) * au;
+                                yp[3 * r + 1] += (AT)f8_decode(c_[(t0 + 3 * r + 1) >> 2], (t0 + 3 * r + 1) & 3) * aw;
+                                yp[3 * r + 2] += (AT)f8_decode(c_[(t0 + 3 * r + 2) >> 2], (t0 + 3 * r + 2) & 3) * ag;
                             }
                         } else {
                             y0 += offd(c_, t0 + 0) * xu + offd(c_, t0 + 1) * xw + offd(c_, t0 + 2) * xg;
@@ -2536,9 +2546,9 @@ __global__ __launch_bounds__(GeoB::THREADS, 3) void k_sweep_st(const typename Co
 #pragma unroll
                 for (int t = 0; t < 9; ++t) Dm[t] = (double)__uint_as_float(dg[t]);
                 if constexpr (F8) {
-                    y0 = yp[0] * (double)f8_unit(dg[9], 0) + yp[1] * (double)f8_unit(dg[9], 1) + yp[2] * (double)f8_unit(dg[9], 2);
-                    y1 = yp[3] * (double)f8_unit(dg[10], 0) + yp[4] * (double)f8_unit(dg[10], 1) + yp[5] * (double)f8_unit(dg[10], 2);
-                    y2 = yp[6] * (double)f8_unit(dg[11], 0) + yp[7] * (double)f8_unit(dg[11], 1) + yp[8] * (double)f8_unit(dg[11], 2);
+                    y0 = (double)yp[0] * (double)f8_unit(dg[9], 0) + (double)yp[1] * (double)f8_unit(dg[9], 1) + (double)yp[2] * (double)f8_unit(dg[9], 2);
+                    y1 = (double)yp[3] * (double)f8_unit(dg[10], 0) + (double)yp[4] * (double)f8_unit(dg[10], 1) + (double)yp[5] * (double)f8_unit(dg[10], 2);
+                    y2 = (double)yp[6] * (double)f8_unit(dg[11], 0) + (double)yp[7] * (double)f8_unit(dg[11], 1) + (double)yp[8] * (double)f8_unit(dg[11], 2);
                 }
                 double u, w, gm;
                 solve3(Dm, (double)bq[0] - y0, (double)bq[1] - y1, (double)bq[2] - y2, u, w, gm);
