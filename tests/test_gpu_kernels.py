@@ -100,6 +100,8 @@ def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, be
             y = s.debug_apply(lvl, x)
             for k in range(npairs):
                 assert relerr(y[k], mg.apply_stencil(H[k].levels[lvl], x[k])) < max(tol, 1e-12)
+                # the stencil as the host unpacks it is the operator the device kernels apply (packed formats: the decoders agree)
+                assert relerr(y[k], mg.apply_stencil(Cg[k], x[k])) < 1e-13
             if coarse_precision == 0:
                 xg, xr = x.copy(), x.copy()
                 for colour in (0, 1, 2, 3):
