@@ -183,6 +183,12 @@ __device__ __forceinline__ double coef_at(const typename CoefFmt<CT>::word_t* __
 struct PixCoef {
     double P, Dx, Dy, Dxx, Dyy, Dxy;
 };
+struct PixCoefF {   // the same rounded to float32 (evaluated from the image in float64)
+    float P, Dx, Dy, Dxx, Dyy, Dxy;
+    __device__ __forceinline__ PixCoefF() {}
+    __device__ __forceinline__ explicit PixCoefF(const PixCoef& k)
+        : P((float)k.P), Dx((float)k.Dx), Dy((float)k.Dy), Dxx((float)k.Dxx), Dyy((float)k.Dyy), Dxy((float)k.Dxy) {}
+};
 
 // I points at the pair's previous frame (full grid, pitch Nj); (p, q) are interior indices.
 __device__ __forceinline__ PixCoef pix_coef(const double* __restrict__ I, int Nj, int p, int q, int quirks) {
@@ -201,9 +207,10 @@ __device__ __forceinline__ PixCoef pix_coef(const double* __restrict__ I, int Nj
 }
 
 // blk[r*3+c] += scale * (raw 3x3 block of offset (oi, oj)), OF.py:843-960.
-__device__ __forceinline__ void add_raw_block(const PixCoef& k, double alpha, double beta, int oi, int oj,
-                                              double scale, double* blk) {
-    const double P = k.P;
+// (T = double, or float with a PixCoefF: the level-0 Galerkin product of the 32-bit stencil formats)
+template <typename T, typename KT>
+__device__ __forceinline__ void add_raw_block(const KT& k, T alpha, T beta, int oi, int oj, T scale, T* blk) {
+    const T P = k.P;
     if (oi == 0 && oj == 0) {
         blk[0] += scale * (P * (k.Dxx + -2 * P) - 4 * alpha);
         blk[1] += scale * (P * k.Dxy);
@@ -213,7 +220,7 @@ __device__ __forceinline__ void add_raw_block(const PixCoef& k, double alpha, do
         blk[7] += scale * k.Dy;
         blk[8] += scale * (-1 - 4 * beta);
     } else if (oj == 0) {  // (+-1, 0)
-        double s = (double)oi;
+        T s = (T)oi;
         blk[0] += scale * (P * (s * k.Dx + P) + alpha);
         blk[1] += scale * (s * P * k.Dy / 2);
         blk[2] += scale * (-s * P / 2);
@@ -222,7 +229,7 @@ __device__ __forceinline__ void add_raw_block(const PixCoef& k, double alpha, do
         blk[6] += scale * (s * P / 2);
         blk[8] += scale * beta;
     } else if (oi == 0) {  // (0, +-1)
-        double s = (double)oj;
+        T s = (T)oj;
         blk[0] += scale * alpha;
         blk[1] += scale * (s * P * k.Dx / 2);
         blk[3] += scale * (s * P * k.Dx / 2);
@@ -231,7 +238,7 @@ __device__ __forceinline__ void add_raw_block(const PixCoef& k, double alpha, do
         blk[7] += scale * (s * P / 2);
         blk[8] += scale * beta;
     } else {  // diagonals: +P^2/4 for (-1,-1),(+1,+1); -P^2/4 for the other two
-        double s = (double)(oi * oj);
+        T s = (T)(oi * oj);
         blk[1] += scale * (s * P * P / 4);
         blk[3] += scale * (s * P * P / 4);
     }
@@ -247,16 +254,16 @@ __host__ __device__ constexpr unsigned raw_block_mask(int oi, int oj) {
 
 // Folded block of offset (oi, oj) at interior point (p, q): the ghost couplings are added onto the
 // interior point they mirror to.  The target (p+oi, q+oj) must be inside the grid.
-__device__ __forceinline__ void folded_block(const PixCoef& k, double alpha, double beta, int p, int q, int ni,
-                                             int nj, int oi, int oj, double* blk) {
+template <typename T, typename KT>
+__device__ __forceinline__ void folded_block(const KT& k, T alpha, T beta, int p, int q, int ni, int nj, int oi, int oj, T* blk) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) blk[t] = 0.0;
+    for (int t = 0; t < 9; ++t) blk[t] = (T)0;
     bool gi = (oi == 1 && p == 0) || (oi == -1 && p == ni - 1);  // ghost -oi folds onto +oi
     bool gj = (oj == 1 && q == 0) || (oj == -1 && q == nj - 1);
-    add_raw_block(k, alpha, beta, oi, oj, 1.0, blk);
-    if (gi) add_raw_block(k, alpha, beta, -oi, oj, 1.0, blk);
-    if (gj) add_raw_block(k, alpha, beta, oi, -oj, 1.0, blk);
-    if (gi && gj) add_raw_block(k, alpha, beta, -oi, -oj, 2.0, blk);  // corner ghost = 2 x(2,2)
+    add_raw_block(k, alpha, beta, oi, oj, (T)1, blk);
+    if (gi) add_raw_block(k, alpha, beta, -oi, oj, (T)1, blk);
+    if (gj) add_raw_block(k, alpha, beta, oi, -oj, (T)1, blk);
+    if (gi && gj) add_raw_block(k, alpha, beta, -oi, -oj, (T)2, blk);  // corner ghost = 2 x(2,2)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -824,74 +831,95 @@ __global__ __launch_bounds__(NT) void k_galerkin(const double* __restrict__ fram
     if (LEVEL0 && pp) { alpha = pp[pair].alpha; beta = pp[pair].beta; fidx = pp[pair].frame; }
     const CLay Lf(nfi, nfj), Lc(nci, ncj);
     const size_t nf = Lf.plane, nc = Lc.plane;
-    // float32 / bfloat16 stencils are accumulated in float32 (preconditioner data: the <= 36 terms per entry lose ~1e-6
-    // relative; FP32 FMAs issue at twice the FP64 rate and this kernel is FMA-bound); the fine blocks themselves are
-    // evaluated from the image in float64
+    // the 32-bit stencil formats are accumulated in float32 (preconditioner data: the <= 36 terms per entry lose ~1e-6
+    // relative; FP32 FMAs issue at twice the FP64 rate and this kernel is FMA-bound), and the fine blocks of level 0 are
+    // evaluated in float32 as well, from image derivatives computed in float64 (a third of the kernel's instructions were
+    // float64 block arithmetic and conversions)
     typedef typename std::conditional<std::is_same<CTC, double>::value, double, float>::type AT;
     AT acc[9][9];
 #pragma unroll
     for (int d = 0; d < 9; ++d)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[d][t] = (AT)0;
+    // Coarse points away from the border (all but a frame of one or two points) take a path without any of the existence
+    // tests, ghost folds and orphan weights: every prolongation weight is then a compile-time constant (1 or 1/2 per
+    // direction), every loop bound is static and the fine blocks are the raw ones.
+    const bool interior = cp >= 1 && cp + 1 < nci && 2 * cp + 1 <= nfi - 2 && cq >= 1 && cq + 1 < ncj && 2 * cq + 1 <= nfj - 2;
+    auto accumulate = [&](auto interior_tag) {
+        constexpr bool IN = decltype(interior_tag)::value;
 #pragma unroll
-    for (int fi = -1; fi <= 1; ++fi) {
-        const int fp = 2 * cp + fi;
-        if (fp < 0 || fp >= nfi) continue;
-        const double wfi = pweight(fp, cp, nci);
+        for (int fi = -1; fi <= 1; ++fi) {
+            const int fp = 2 * cp + fi;
+            if (!IN && (fp < 0 || fp >= nfi)) continue;
+            const double wfi = IN ? (fi == 0 ? 1.0 : 0.5) : pweight(fp, cp, nci);
 #pragma unroll
-        for (int fj = -1; fj <= 1; ++fj) {
-            const int fq = 2 * cq + fj;
-            if (fq < 0 || fq >= nfj) continue;
-            const double wf = wfi * pweight(fq, cq, ncj);
-            PixCoef k;
-            CoefSet<CTF> fs;   // the fine point's stored stencil (levels >= 1)
-            if (LEVEL0) k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, fp, fq, quirks);
-            else fs.load(Cf + (size_t)pair * CoefFmt<CTF>::PLANES * nf + Lf.idx(fp, fq), nf);
+            for (int fj = -1; fj <= 1; ++fj) {
+                const int fq = 2 * cq + fj;
+                if (!IN && (fq < 0 || fq >= nfj)) continue;
+                const double wf = wfi * (IN ? (fj == 0 ? 1.0 : 0.5) : pweight(fq, cq, ncj));
+                PixCoef k;
+                PixCoefF kf;
+                CoefSet<CTF> fs;   // the fine point's stored stencil (levels >= 1)
+                if (LEVEL0) { k = pix_coef(frames + (size_t)fidx * frame_stride, Nj, fp, fq, quirks); kf = PixCoefF(k); }
+                else fs.load(Cf + (size_t)pair * CoefFmt<CTF>::PLANES * nf + Lf.idx(fp, fq), nf);
 #pragma unroll
-            for (int oi = -1; oi <= 1; ++oi) {
-                const int gp = fp + oi;
-                if (gp < 0 || gp >= nfi) continue;
+                for (int oi = -1; oi <= 1; ++oi) {
+                    const int gp = fp + oi;
+                    if (!IN && (gp < 0 || gp >= nfi)) continue;
 #pragma unroll
-                for (int oj = -1; oj <= 1; ++oj) {
-                    const int gq = fq + oj;
-                    if (gq < 0 || gq >= nfj) continue;
-                    AT blk[9];
-                    if (LEVEL0) {
-                        double blk64[9];
-                        folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk64);
+                    for (int oj = -1; oj <= 1; ++oj) {
+                        const int gq = fq + oj;
+                        if (!IN && (gq < 0 || gq >= nfj)) continue;
+                        AT blk[9];
+                        if (LEVEL0) {
+                            if (IN) {   // no ghost neighbour anywhere near: the raw block
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) blk[t] = (AT)blk64[t];
-                    } else {
+                                for (int t = 0; t < 9; ++t) blk[t] = (AT)0;
+                                if constexpr (std::is_same<AT, float>::value) add_raw_block(kf, (float)alpha, (float)beta, oi, oj, 1.0f, blk);
+                                else add_raw_block(k, alpha, beta, oi, oj, 1.0, blk);
+                            } else {
+                                if constexpr (std::is_same<AT, float>::value) folded_block(kf, (float)alpha, (float)beta, fp, fq, nfi, nfj, oi, oj, blk);
+                                else folded_block(k, alpha, beta, fp, fq, nfi, nfj, oi, oj, blk);
+                            }
+                        } else {
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) blk[t] = (AT)fs.get(((oi + 1) * 3 + (oj + 1)) * 9 + t);
-                    }
+                            for (int t = 0; t < 9; ++t) blk[t] = (AT)fs.get(((oi + 1) * 3 + (oj + 1)) * 9 + t);
+                        }
 #pragma unroll
-                    for (int a = -1; a <= 1; ++a) {
-                        // g - 2 D = (fi + oi) - 2 a must be in {-1, 0, 1}: decided at compile time
-                        const int ti = fi + oi - 2 * a;
-                        if (ti < -1 || ti > 1) continue;
-                        const int Dp = cp + a;
-                        if (Dp < 0 || Dp >= nci) continue;
-                        const double wgi = pweight(gp, Dp, nci);
+                        for (int a = -1; a <= 1; ++a) {
+                            // g - 2 D = (fi + oi) - 2 a must be in {-1, 0, 1}: decided at compile time
+                            const int ti = fi + oi - 2 * a;
+                            if (ti < -1 || ti > 1) continue;
+                            const int Dp = cp + a;
+                            if (!IN && (Dp < 0 || Dp >= nci)) continue;
+                            const double wgi = IN ? (ti == 0 ? 1.0 : 0.5) : pweight(gp, Dp, nci);
 #pragma unroll
-                        for (int b = -1; b <= 1; ++b) {
-                            const int tj = fj + oj - 2 * b;
-                            if (tj < -1 || tj > 1) continue;
-                            const int Dq = cq + b;
-                            if (Dq < 0 || Dq >= ncj) continue;
-                            const AT w = (AT)(wf * wgi * pweight(gq, Dq, ncj));
+                            for (int b = -1; b <= 1; ++b) {
+                                const int tj = fj + oj - 2 * b;
+                                if (tj < -1 || tj > 1) continue;
+                                const int Dq = cq + b;
+                                if (!IN && (Dq < 0 || Dq >= ncj)) continue;
+                                const AT w = (AT)(wf * wgi * (IN ? (tj == 0 ? 1.0 : 0.5) : pweight(gq, Dq, ncj)));
 #pragma unroll
-                            for (int t = 0; t < 9; ++t) {
-                                // level 0: only 43 of the 81 entries of a point's nine blocks can be non-zero (OF.py:843-960;
-                                // folding a ghost block onto its mirror keeps the pattern) - the others are skipped at compile time
-                                if (LEVEL0 && !((raw_block_mask(oi, oj) >> t) & 1u)) continue;
-                                acc[(a + 1) * 3 + (b + 1)][t] += w * blk[t];
+                                for (int t = 0; t < 9; ++t) {
+                                    // level 0: only 43 of the 81 entries of a point's nine blocks can be non-zero (OF.py:843-960;
+                                    // folding a ghost block onto its mirror keeps the pattern) - the others are skipped at compile time
+                                    if (LEVEL0 && !((raw_block_mask(oi, oj) >> t) & 1u)) continue;
+                                    acc[(a + 1) * 3 + (b + 1)][t] += w * blk[t];
+                                }
                             }
                         }
                     }
                 }
             }
         }
+    };
+    // (level 0 only: on the stored levels the compiler hoists the stencil loads of all nine fine points out of the straight-line
+    // path - 256 registers + spills)
+    if constexpr (LEVEL0) {
+        if (interior) accumulate(std::true_type{}); else accumulate(std::false_type{});
+    } else {
+        accumulate(std::false_type{});
     }
     typename CoefFmt<CTC>::word_t* out = Cc + (size_t)pair * CoefFmt<CTC>::PLANES * nc + Lc.idx(cp, cq);
     if constexpr (std::is_same<CTC, CoefB16>::value) {
