@@ -117,7 +117,23 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *                              (default: k_sweep0m, two sweeps per pass)
  *   VOF_COARSEST_MAX=3..9      coarsen until max(n_i, n_j) <= this (default 5); changes the hierarchy depth, hence iteration counts
  *   VOF_COARSE_TAIL=0          levels whose whole grid fits one workgroup: one launch per operation instead of the fused
- *                              LDS-resident coarse-tail kernel */
+ *                              LDS-resident coarse-tail kernel
+ *   VOF_FUSE_RESU=0            stored levels: stand-alone residual + restriction kernels instead of the coarse right-hand side
+ *                              from the last sweep's update (k_resrestrict_u)
+ *   VOF_SWEEP_ST=0             stored levels, packed stencil formats: the generic k_sweep instead of k_sweep_st
+ *   VOF_FOLD_STORED=1          stored levels: coarse-grid correction interpolated inside the first post-sweep
+ *   VOF_SKIP_COLOUR0=0         W-cycle revisits: full first pre-smoothing sweep (default: colour 0 is left alone, same bits)
+ *   VOF_TRACE=1                direct preconditioner: progress lines on stderr
+ * Debug switches (fault attribution; they change timing, never results):
+ *   VOF_DEBUG_SYNC=1           the context's stream is synchronised and asked for its error after every launch scope; the
+ *                              first failure is reported on stderr and appended to every later error text as
+ *                              "scope #n, kernel class 'name', level l, pairs, image size: error"
+ *   VOF_DEBUG_SYNC_FILE=path   (with VOF_DEBUG_SYNC) the scope about to be waited for is written to this file first, so that
+ *                              a process the driver aborts leaves the name of the launch that was in flight
+ *   VOF_DEBUG_CANARY=1         every device buffer of the context is allocated between two 4-KiB guard regions of a known byte
+ *                              pattern, checked by vof_debug_check_canaries and vof_destroy (out-of-bounds WRITES are named
+ *                              by buffer and offset)
+ *   VOF_DEBUG_ALLOC_LOG=1      base, end, size and name of every device buffer on stderr (maps a faulting address to a buffer) */
 
 /* One context = one device = one host thread at a time.  Owns device workspaces for images of
  * (n_i, n_j) and up to max_pairs_in_flight frame pairs solved concurrently (batch dimension).
@@ -193,7 +209,8 @@ int vof_texture_stack_dev(vof_ctx* ctx, double* out_dev, int n_frames, const dou
 int vof_set_fused_sweeps(vof_ctx* ctx, int on);
 
 /* Fixed-work kernel benchmark (SURVEY 8(d) "fixed sweep count"): n_sweeps full 4-colour block-GS
- * sweeps of the fine level on n_pairs pairs of a device-resident movie.  Used by bench.py. */
+ * sweeps of the fine level on n_pairs pairs of a device-resident movie.  Used by scripts/gpu_sweep_micro.py and
+ * scripts/gpu_sweep_shape.py (bench.py times the whole solve and reads the per-class profiler instead). */
 int vof_bench_sweeps_dev(vof_ctx* ctx, const double* movie, int n_pairs, const vof_params* p, int n_sweeps);
 
 /* Built-in profiler: when enabled, every kernel launch is bracketed by HIP events on the
@@ -220,6 +237,8 @@ const char* vof_kernel_name(int kernel_id);
  * All vectors are interior-grid vectors of level `level`, layout [pair][3][n_i(level)][n_j(level)].
  * vof_debug_setup must be called first (uploads frames, builds the Galerkin hierarchy). */
 int vof_debug_setup(vof_ctx* ctx, const double* movie_host, int n_pairs, const vof_params* p);
+/* 0: all guard regions intact (or VOF_DEBUG_CANARY off); -5: damaged, vof_last_error names buffer and offset */
+int vof_debug_check_canaries(vof_ctx* ctx);
 int vof_debug_level_shape(vof_ctx* ctx, int level, int* n_i, int* n_j);
 int vof_debug_rhs(vof_ctx* ctx, double* b_host);                                   /* level 0 */
 int vof_debug_apply(vof_ctx* ctx, int level, const double* x_host, double* y_host); /* y = A_l x */

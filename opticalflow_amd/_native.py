@@ -81,6 +81,7 @@ SIGNATURES = {
     "vof_profile_get_moved": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "vof_kernel_name": (C.c_char_p, [C.c_int]),
     "vof_debug_setup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams)]),
+    "vof_debug_check_canaries": (C.c_int, [_vp]),
     "vof_debug_level_shape": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vof_debug_rhs": (C.c_int, [_vp, _vp]),
     "vof_debug_apply": (C.c_int, [_vp, C.c_int, _vp, _vp]),
@@ -186,10 +187,18 @@ class Solver:
         self.h = h
 
     # -- lifetime
+    def check_canaries(self):
+        """VOF_DEBUG_CANARY=1: raises VofError naming the buffer if a kernel wrote outside one (no-op otherwise)."""
+        self._check(self.lib.vof_debug_check_canaries(self.h), "vof_debug_check_canaries")
+
     def close(self):
         if getattr(self, "h", None):
-            self.lib.vof_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            rc = self.lib.vof_debug_check_canaries(h)
+            msg = self.lib.vof_last_error(h).decode() if rc != 0 else ""
+            self.lib.vof_destroy(h)
+            if rc != 0:
+                raise VofError("device buffer guard regions damaged: " + msg)
 
     def __del__(self):
         try:

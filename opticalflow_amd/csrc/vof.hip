@@ -11,6 +11,8 @@
 #include "../../include/vof.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -87,6 +89,7 @@ struct vof_ctx {
     int* h_active = nullptr;
     PairScalars* h_sc = nullptr;
     double* h_func3 = nullptr;
+    char* h_bounce = nullptr;        // pinned bounce buffer of the debug / test entry points (lazy)
     // staging for the host-pointer API (allocated lazily)
     double* st_movie = nullptr;
     double* st_out[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -157,17 +160,51 @@ struct vof_ctx {
     double prof_bytes[VOF_K_COUNT][16];
     double prof_moved[VOF_K_COUNT][16];
     int cur_units = 0;  // frame pairs the next launches process (active pairs of the batch)
+    // fault attribution (see the "debug switches" paragraph of include/vof.h)
+    int dbg_sync = 0;            // VOF_DEBUG_SYNC=1: synchronise + check after every launch scope; the first failure names its kernel class
+    long long dbg_seq = 0;       // launch scopes checked so far
+    std::string dbg_fault;       // the first failure
+    int dbg_fd = -1;             // VOF_DEBUG_SYNC_FILE: the scope in flight is written here before it is waited for (survives an abort)
+    bool dbg_canary = false;     // VOF_DEBUG_CANARY=1: every device buffer sits between two guard pages of a known pattern
+    bool dbg_alloc_log = false;  // VOF_DEBUG_ALLOC_LOG=1: base / size / name of every device buffer on stderr
+    bool dbg_poison = false;     // VOF_DEBUG_POISON=1: every new device buffer is filled with 0xFF bytes (NaN as float / double, -1 as int)
+    struct DbgAlloc { void* raw; char* user; size_t bytes; const char* name; int line; };
+    std::vector<DbgAlloc> dbg_allocs;
 };
 
 static std::string g_create_error;
 
 namespace {
 
+// VOF_DEBUG_SYNC: wait for the launches of the scope that has just ended and ask for their error, so that a fault is
+// reported against the kernel class and level that caused it instead of at some later synchronising call.
+void dbg_sync_check(vof_ctx* c, const char* what, int level) {
+    if (!c->dbg_sync) return;
+    ++c->dbg_seq;
+    char line[256];
+    if (c->dbg_fd >= 0) {
+        int n = snprintf(line, sizeof line, "in flight: scope #%lld '%s' level %d, %d pairs, grid %dx%d (%d levels)%-40s\n", c->dbg_seq, what, level,
+                         c->cur_units, c->Ni, c->Nj, (int)c->L.size(), "");
+        if (pwrite(c->dbg_fd, line, (size_t)n, 0) < 0) { /* diagnostics only */ }
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e2 = hipGetLastError();
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess && c->dbg_fault.empty()) {
+        snprintf(line, sizeof line, "VOF_DEBUG_SYNC: scope #%lld, kernel class '%s', level %d, %d pairs, image %dx%d: %s", c->dbg_seq, what, level,
+                 c->cur_units, c->Ni, c->Nj, hipGetErrorString(e));
+        c->dbg_fault = line;
+        fprintf(stderr, "%s\n", line);
+        fflush(stderr);
+    }
+}
+
 struct Prof {
     vof_ctx* c;
     bool on;
+    int dkid, dlevel;
     ProfRec rec;
-    Prof(vof_ctx* c_, int kid, int level, double bytes_per_pair = 0.0, double moved_per_pair = -1.0) : c(c_), on(false) {
+    Prof(vof_ctx* c_, int kid, int level, double bytes_per_pair = 0.0, double moved_per_pair = -1.0) : c(c_), on(false), dkid(kid), dlevel(level) {
         if (!c->prof) return;
         if (c->prof_kid >= 0 && kid != c->prof_kid) return;
         if (c->prof_level >= 0 && level != c->prof_level) return;
@@ -186,9 +223,11 @@ struct Prof {
         hipEventRecord(rec.e0, c->stream);
     }
     ~Prof() {
-        if (!on) return;
-        hipEventRecord(rec.e1, c->stream);
-        c->recs.push_back(rec);
+        if (on) {
+            hipEventRecord(rec.e1, c->stream);
+            c->recs.push_back(rec);
+        }
+        if (c->dbg_sync) dbg_sync_check(c, vof_kernel_name(dkid), dlevel);
     }
 };
 
@@ -217,19 +256,60 @@ void prof_collect(vof_ctx* c) {
             char buf_[512];                                                                        \
             snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
             c->err = buf_;                                                                         \
+            if (!c->dbg_fault.empty()) c->err += " [" + c->dbg_fault + "]";                        \
             return -2;                                                                             \
         }                                                                                          \
     } while (0)
 
+constexpr size_t DBG_GUARD = 4096;        // bytes of guard pattern on either side of a buffer (VOF_DEBUG_CANARY=1)
+constexpr int DBG_GUARD_BYTE = 0xC5;
+
 template <typename T>
-int dev_alloc(vof_ctx* c, T** p, size_t n) {
+int dev_alloc_named(vof_ctx* c, T** p, size_t n, const char* name, int line) {
     void* q = nullptr;
     size_t bytes = std::max<size_t>(n * sizeof(T), 256);
-    HIPCHK(hipMalloc(&q, bytes));
-    c->allocs.push_back(q);
+    if (c->dbg_canary) {
+        HIPCHK(hipMalloc(&q, bytes + 2 * DBG_GUARD));
+        HIPCHK(hipMemset(q, DBG_GUARD_BYTE, DBG_GUARD));
+        HIPCHK(hipMemset((char*)q + DBG_GUARD + bytes, DBG_GUARD_BYTE, DBG_GUARD));
+        c->allocs.push_back(q);
+        c->dbg_allocs.push_back({q, (char*)q + DBG_GUARD, bytes, name, line});
+        *p = (T*)((char*)q + DBG_GUARD);
+    } else {
+        HIPCHK(hipMalloc(&q, bytes));
+        c->allocs.push_back(q);
+        *p = (T*)q;
+    }
     c->bytes += bytes;
-    *p = (T*)q;
+    if (c->dbg_poison) HIPCHK(hipMemset(*p, 0xFF, bytes));
+    if (c->dbg_alloc_log)
+        fprintf(stderr, "vof alloc ctx=%p %s (vof.hip:%d) base=%p end=%p bytes=%zu\n", (void*)c, name, line, (void*)*p, (void*)((char*)*p + bytes), bytes);
     return 0;
+}
+#define dev_alloc(c, p, n) dev_alloc_named(c, p, n, #p, __LINE__)
+
+// Guard pages of every buffer of the context against their pattern; the number of damaged buffers, each named in `report`.
+int dbg_check_canaries(vof_ctx* c, std::string* report) {
+    int bad = 0;
+    std::vector<unsigned char> h(2 * DBG_GUARD);
+    for (const auto& a : c->dbg_allocs) {
+        if (hipMemcpy(h.data(), a.raw, DBG_GUARD, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h.data() + DBG_GUARD, a.user + a.bytes, DBG_GUARD, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (report) *report += "guard pages unreadable; ";
+            return -1;
+        }
+        long first_lo = -1, first_hi = -1;
+        for (size_t i = 0; i < DBG_GUARD; ++i) if (h[DBG_GUARD - 1 - i] != DBG_GUARD_BYTE) { first_lo = (long)i + 1; break; }   // bytes BELOW the buffer
+        for (size_t i = 0; i < DBG_GUARD; ++i) if (h[DBG_GUARD + i] != DBG_GUARD_BYTE) { first_hi = (long)i; break; }            // bytes PAST its end
+        if (first_lo >= 0 || first_hi >= 0) {
+            ++bad;
+            char line[256];
+            snprintf(line, sizeof line, "buffer %s (vof.hip:%d, %zu bytes at %p): written %s%ld bytes %s; ", a.name, a.line, a.bytes, (void*)a.user,
+                     first_hi >= 0 ? "" : "-", first_hi >= 0 ? first_hi : first_lo, first_hi >= 0 ? "past its end" : "before its start");
+            if (report) *report += line;
+        }
+    }
+    return bad;
 }
 
 inline dim3 grid2d(int ni, int nj, int z) { return dim3((nj + BX - 1) / BX, (ni + BY - 1) / BY, z); }
@@ -825,6 +905,7 @@ int setup_batch(vof_ctx* c, const double* frames_dev, int np) {
     {
         Prof p(c, VOF_K_COARSE_SETUP, nl - 1);
         CDISPATCH(c, nl - 1, (k_coarse_build<CT><<<np, 256, 0, c->stream>>>((const CW*)last.C, last.ni, last.nj, c->W)));
+        dbg_sync_check(c, "coarse_build", nl - 1);
         k_coarse_invert<<<np, 1024, 0, c->stream>>>(c->W, c->nd, c->invT);
     }
     HIPCHK(hipGetLastError());
@@ -873,6 +954,7 @@ int gmres_phase(vof_ctx* c, int np, int* handed_over) {
         if (int rc = dev_alloc(c, &c->gm_cycle, (size_t)c->B)) return rc;
     }
     k_gm_begin<<<(np + 63) / 64, 64, 0, s>>>(c->sc, c->active, c->gm_cycle, np, P.max_iterations);
+    dbg_sync_check(c, "gm_begin", 0);
     int nact = count_active(c, np);
     if (nact < 0) { c->err = "stream synchronize failed"; return -2; }
     if (nact == 0) return 0;
@@ -1391,13 +1473,23 @@ const char* vof_kernel_name(int k) {
 void vof_destroy(vof_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) {
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && (c->dbg_sync || c->dbg_canary))
+            fprintf(stderr, "vof_destroy: the context's stream ends with an error: %s\n", hipGetErrorString(e));
+    }
+    if (c->dbg_canary) {
+        std::string rep;
+        if (dbg_check_canaries(c, &rep) != 0) { fprintf(stderr, "vof_destroy: VOF_DEBUG_CANARY: %s\n", rep.c_str()); fflush(stderr); }
+    }
+    if (c->dbg_fd >= 0) close(c->dbg_fd);
     prof_collect(c);
     for (auto e : c->free_events) hipEventDestroy(e);
     for (void* p : c->allocs) hipFree(p);
     if (c->h_active) hipHostFree(c->h_active);
     if (c->h_sc) hipHostFree(c->h_sc);
     if (c->h_func3) hipHostFree(c->h_func3);
+    if (c->h_bounce) hipHostFree(c->h_bounce);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_solved[i]) hipEventDestroy(c->ev_solved[i]);
         if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]);
@@ -1425,6 +1517,12 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     memset(c->prof_bytes, 0, sizeof c->prof_bytes);
     memset(c->prof_moved, 0, sizeof c->prof_moved);
     vof_default_params(&c->prm, sizeof c->prm);
+    if (const char* e = getenv("VOF_DEBUG_SYNC")) c->dbg_sync = atoi(e);
+    if (const char* e = getenv("VOF_DEBUG_CANARY")) c->dbg_canary = e[0] != '0';
+    if (const char* e = getenv("VOF_DEBUG_ALLOC_LOG")) c->dbg_alloc_log = e[0] != '0';
+    if (const char* e = getenv("VOF_DEBUG_POISON")) c->dbg_poison = e[0] != '0';
+    if (c->dbg_sync)
+        if (const char* e = getenv("VOF_DEBUG_SYNC_FILE")) c->dbg_fd = open(e, O_WRONLY | O_CREAT, 0644);
     if (const char* e = getenv("VOF_SWEEP_GEO")) {   // experiment switch: "AA", "AB" (default), "BA", "BB" = fine,stored
         c->geo_b_fine = e[0] == 'B';
         c->geo_b_stored = e[0] && e[1] == 'B';
@@ -2220,6 +2318,16 @@ int vof_debug_setup(vof_ctx* c, const double* movie_host, int n_pairs, const vof
     return 0;
 }
 
+int vof_debug_check_canaries(vof_ctx* c) {
+    if (!c) return -1;
+    if (!c->dbg_canary) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::string rep;
+    const int bad = dbg_check_canaries(c, &rep);
+    if (bad != 0) { c->err = "VOF_DEBUG_CANARY: " + rep; return -5; }
+    return 0;
+}
+
 int vof_debug_level_shape(vof_ctx* c, int level, int* n_i, int* n_j) {
     if (!c) return -1;
     if (level < 0 || level >= (int)c->L.size()) { c->err = "bad level"; return -1; }
@@ -2234,6 +2342,21 @@ int vof_debug_level_shape(vof_ctx* c, int level, int* n_i, int* n_j) {
     Level& lv = c->L[level];                                                          \
     size_t nbytes = (size_t)c->npairs * 3 * lv.npts * sizeof(double);                 \
     (void)nbytes;
+
+// Device -> pageable host memory through a pinned bounce buffer on the context's stream (the debug entry points used the
+// runtime's blocking hipMemcpy on the null stream, which pins the destination on the fly for copies above 1 MiB).
+constexpr size_t BOUNCE_BYTES = (size_t)8 << 20;
+static int d2h_bounced(vof_ctx* c, void* host, const void* dev, size_t bytes) {
+    if (!c->h_bounce) HIPCHK(hipHostMalloc((void**)&c->h_bounce, BOUNCE_BYTES));
+    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+        const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+        HIPCHK(hipMemcpyAsync(c->h_bounce, (const char*)dev + off, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy((char*)host + off, c->h_bounce, n);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 
 // The debug API moves host float64 arrays in and out of V-typed device buffers (kp, kv, kt; staging: krh).
 static int dbg_up(vof_ctx* c, void* dst_v, const double* host, size_t n) {
@@ -2369,7 +2492,7 @@ int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
     };
     if (fmt == 2) {   // 36 planes of packed bfloat16 pairs (off-diagonal blocks) + 9 float32 planes (diagonal block)
         std::vector<uint32_t> tw(n);
-        HIPCHK(hipMemcpy(tw.data(), lv.C, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (int rc = d2h_bounced(c, tw.data(), lv.C, n * sizeof(uint32_t))) return rc;
         unpack([&](size_t base, int pl, size_t idx) -> double {
             const int d = pl / 9, e = pl % 9;
             uint32_t bits;
@@ -2385,7 +2508,7 @@ int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
         });
     } else if (fmt == 3) {   // 18 planes of four 8-bit floats (1-4-3, bias 7, no infinities) + 9 float32 planes + 3 planes of units
         std::vector<uint32_t> tw(n);
-        HIPCHK(hipMemcpy(tw.data(), lv.C, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (int rc = d2h_bounced(c, tw.data(), lv.C, n * sizeof(uint32_t))) return rc;
         unpack([&](size_t base, int pl, size_t idx) -> double {
             const int d = pl / 9, e = pl % 9;
             if (d == 4) {
@@ -2402,11 +2525,11 @@ int vof_debug_stencil(vof_ctx* c, int level, double* c_host) {
         });
     } else if (fmt == 1) {
         std::vector<float> tf(n);
-        HIPCHK(hipMemcpy(tf.data(), lv.C, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (int rc = d2h_bounced(c, tf.data(), lv.C, n * sizeof(float))) return rc;
         unpack([&](size_t base, int pl, size_t idx) -> double { return tf[base + (size_t)pl * L.plane + idx]; });
     } else {
         std::vector<double> tmp(n);
-        HIPCHK(hipMemcpy(tmp.data(), lv.C, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (int rc = d2h_bounced(c, tmp.data(), lv.C, n * sizeof(double))) return rc;
         unpack([&](size_t base, int pl, size_t idx) -> double { return tmp[base + (size_t)pl * L.plane + idx]; });
     }
     return 0;
@@ -2439,7 +2562,7 @@ int vof_debug_vcycle_apply(vof_ctx* c, const double* r_host, double* y_host, dou
     std::vector<double> part((size_t)np * 3 * nb);
     HIPCHK(hipMemcpyAsync(part.data(), c->partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (int rc = dbg_down(c, y_host, c->ky, n)) return rc;
-    HIPCHK(hipMemcpy(v_host, c->kv, nbytes, hipMemcpyDeviceToHost));
+    if (int rc = d2h_bounced(c, v_host, c->kv, nbytes)) return rc;
     for (int k = 0; k < np; ++k)
         for (int sl = 0; sl < 2; ++sl) {
             double a = 0;
