@@ -83,7 +83,8 @@ def cpu_baseline(size, seed):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = host_cores
-    workers = max(1, min(usable, 16))           # the GPU box gives one GPU's job a 16-core share
+    cap = int(os.environ.get("VOF_BENCH_CPU_WORKERS", "16"))   # the GPU box gives one GPU's job a 16-core share (its affinity
+    workers = max(1, min(usable, cap))                         # mask still lists every core of the host)
     all_cores = None
     try:
         with mp.get_context("spawn").Pool(workers) as pool:
@@ -91,6 +92,8 @@ def cpu_baseline(size, seed):
             per = pool.map(_cpu_pair, [(size, seed, crop, k) for k in range(workers)])
             wall = time.time() - t1
         all_cores = {"value": workers / (wall * pix_ratio), "unit": "frame-pairs/s", "cores": workers,
+                     "cores_cap": f"{cap} worker processes = the CPU share of a one-GPU job on the box; the affinity mask "
+                                  f"({usable} cores) is the whole host's (VOF_BENCH_CPU_WORKERS overrides)",
                      "seconds_wall": wall, "seconds_per_pair_mean": float(sum(per) / len(per)),
                      "sample": f"{workers} pairs of the same {crop}x{crop} crop, one per process"}
     except Exception as exc:      # noqa: BLE001 - the single-core figure stands on its own
@@ -197,7 +200,10 @@ def main():
     # all-gather of chunk i lands in place (natural order) while chunk i+1 is solved; one rank: one chunk = the stack.
     sizes = chunk_plan(P, args.gather_chunks) if gather else [P]
     n_chunks = len(sizes)
-    per_pair = _native.query_workspace(n, n, 1)
+    cp_arg = {"float64": 0, "float32": 1, "bfloat16": 2, "float8": 3}[args.coarse_precision]
+    vp_arg = {"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3}[args.vcycle_precision]
+    # the variant runs below widen the stencil storage of the same context up to float64 (the context re-allocates it)
+    per_pair = _native.query_workspace(n, n, 1, cp_arg if (args.no_variants or world > 1 or use_dist) else 0, vp_arg)
     free, total = _native.device_memory(local_rank)
     gathered_bytes = 3 * world * P * n * n * 8 if gather else 0
     B = args.pairs_in_flight or largest_batch(max(sizes), per_pair, 0.7 * free - gathered_bytes)
@@ -304,6 +310,7 @@ def main():
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
     bytes_per_launch = (alg_bytes / cnt) if (cnt and alg_bytes > 0) else (bpp * pix_per_launch if bpp else None)
     achieved = (bytes_per_launch / avg_s) / 1e9 if (bytes_per_launch and cnt) else None
+    achieved_moved = (moved_bytes / cnt / avg_s / 1e9) if (cnt and moved_bytes > 0) else achieved
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     # the PMC passes were taken with all pairs of the stack in one batch; with chunked solves (multi-GPU overlap) a
@@ -335,24 +342,24 @@ def main():
                    "iterations_max": int(stats["iterations"].max()), "iterations_mean": float(stats["iterations"].mean()),
                    "relres_max": float(stats["relative_residual"].max()),
                    "converged": bool(stats["converged"].all())},
-        "roofline": {"bound": "hbm", "kernel": f"{dom_name}@L{dom_level}", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+        # `achieved` = the bytes one launch HAS TO MOVE (every stream read / written once per pass) over the
+        # average launch time from HIP events on the solver's stream; `frac` = achieved / peak is an HBM fraction.  `traffic` is
+        # the PMC figure of the same launch (halo re-reads included) and is to be compared with `bytes_per_launch`.
+        # `effective_per_sweep` counts SURVEY.md 8(d)'s 80 B per pixel for EVERY sweep a pass performs (the level-0 pass performs
+        # two): a rate of work, not of traffic - it may exceed the peak and is not a roofline fraction.
+        "roofline": {"bound": "hbm", "kernel": f"{dom_name}@L{dom_level}", "achieved": achieved_moved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (achieved_moved / HBM_PEAK_GBS) if achieved_moved else None, "traffic": traffic,
+                     "traffic_over_moved": (traffic / (moved_bytes / cnt)) if (traffic and cnt and moved_bytes) else None,
                      "launches": cnt, "pairs_per_launch": (units / cnt) if cnt else None, "avg_launch_us": 1e6 * avg_s if cnt else None,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     # algorithmic bytes = 80 per pixel and SWEEP performed (56 from a zero guess, 86 with
-                     # the interpolated coarse-grid correction).  One pass of the level-0 smoother performs two sweeps
-                     # (temporal blocking in LDS), so it moves about half of that: "moved" is the minimal traffic of the pass,
-                     # the figure `traffic` (PMC) is to be compared with.
-                     "moved_bytes_per_launch": (moved_bytes / cnt) if cnt else None,
-                     "achieved_moved": (moved_bytes / cnt / avg_s / 1e9) if cnt else None,
+                     "bytes_per_launch": (moved_bytes / cnt) if cnt else None,
+                     "effective_per_sweep": {"bytes_per_launch": bytes_per_launch, "rate": achieved, "unit": "GB/s"},
                      "share_of_gpu_time": dom[3] / total_ms,
-                     # the whole solve, not only the dominant kernel: algorithmic bytes of every byte-counted launch of the
-                     # warm-up step(s) over the step time (HIP-event profile of the warm-up; set-up kernels count as time)
-                     "whole_solve": {"algorithmic_bytes_per_step": alg_total / warm_steps,
-                                     "moved_bytes_per_step": moved_total / warm_steps,
-                                     "achieved_moved": moved_total / warm_steps / (dt / args.steps) / 1e9,
-                                     "achieved": alg_total / warm_steps / (1e-3 * 1e3 * dt / args.steps) / 1e9,
-                                     "frac": alg_total / warm_steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                     # the whole solve, not only the dominant kernel: bytes every byte-counted launch of the warm-up step(s)
+                     # has to move over the step time (set-up kernels without a byte count count as time only)
+                     "whole_solve": {"bytes_per_step": moved_total / warm_steps,
+                                     "achieved": moved_total / warm_steps / (dt / args.steps) / 1e9,
+                                     "frac": moved_total / warm_steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                     "effective_per_sweep": alg_total / warm_steps / (dt / args.steps) / 1e9,
                                      "kernel_time_share_with_byte_count": counted_ms / total_ms}},
     }
     if world == 1 and not use_dist and not args.no_variants:
@@ -389,6 +396,26 @@ def main():
             out["variants"]["time_varying_flow_wobble_0.3"] = timed(params, wob)
             out["variants"]["time_varying_flow_wobble_0.3_cold"] = timed(_native.default_params(vcycle_precision=vp, coarse_precision=cp, **cold), wob)
             del wob
+    if world == 1 and not use_dist and not args.no_variants:
+        # the reference's second consumer of the path: vary_regularisation (OF.py:1918-1998) in the shape of its own sweep,
+        # AVOF.py:608-615 - a 20 x 20 logspace(-1, 4) grid of (speed_alpha, remodelling_alpha) on a down-sampled 8-bit
+        # pair with smoothing_sigma = 1; one native call, host arrays in, summary tables out
+        from opticalflow_amd import optical_flow as of
+        from opticalflow_amd.synthetic import texture_stack_numpy
+        vm = np.round(255.0 * texture_stack_numpy(128, 3, seed=7)).astype(np.uint8)
+        grid = np.logspace(-1, 4, 20)
+        vt = []
+        for _ in range(2):           # the first call creates the device context
+            t1 = time.perf_counter()
+            vr = of.vary_regularisation(vm, grid, grid, smoothing_sigma=1.0, return_stats=True)
+            vt.append(time.perf_counter() - t1)
+        out["variants"]["vary_regularisation"] = {
+            "value": grid.size ** 2 / vt[-1], "unit": "combinations/s", "seconds": vt[-1], "seconds_first_call": vt[0],
+            "combinations": int(grid.size ** 2), "converged_all": bool(np.asarray(vr["stats"]["converged_all"]).all()),
+            "max_iterations_used": int(np.asarray(vr["stats"]["max_iterations_used"]).max()),
+            "what": "vary_regularisation(128x128x3 8-bit texture, logspace(-1, 4, 20)^2, smoothing_sigma=1): 400 combinations "
+                    "x 2 frame pairs, AVOF.py:608-615 shape"}
+        of.release_device_memory()
     if world == 1 and not use_dist and not args.no_end_to_end:
         # end-to-end rate of the drop-in call, pageable numpy arrays in and out (the reference's
         # contract), i.e. including the float64 copy, H2D of the movie and D2H of the four result stacks.  Never `value`.

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-VOF_VERSION = 201                          # include/vof.h
+VOF_VERSION = 202                          # include/vof.h
 LIB = os.environ.get("VOF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "opticalflow_amd",
                                                 "csrc", "libvof.so")
 
@@ -30,7 +30,8 @@ class vof_params(C.Structure):             # include/vof.h: struct vof_params
 class vof_pair_stats(C.Structure):         # include/vof.h: struct vof_pair_stats
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("relative_residual", C.c_double),
                 ("L1_functional", C.c_double), ("speed_functional", C.c_double),
-                ("remodelling_functional", C.c_double)]
+                ("remodelling_functional", C.c_double), ("batch_ms", C.c_double), ("batch_pairs", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 def load(path=LIB):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VOF_VERSION 201 /* 0.2.1: vof_params carries its own size and the ABI version; + preconditioner */
+#define VOF_VERSION 202 /* 0.2.2: vof_pair_stats carries the batch time (0.2.1: vof_params carries its own size and the ABI version) */
 
 typedef struct vof_ctx vof_ctx;
 
@@ -86,6 +86,12 @@ typedef struct vof_pair_stats {
     double L1_functional;      /* OF.py:1178-1180 */
     double speed_functional;   /* OF.py:1181-1182 (the true one; the dict-level bug is applied by the caller) */
     double remodelling_functional; /* OF.py:1183 */
+    double batch_ms;           /* GPU time (HIP events on the solver's stream) of the batch this pair was solved in: hierarchy
+                                  set-up + Krylov iteration + epilogue of batch_pairs pairs advancing together, i.e. this
+                                  pair's share is batch_ms / batch_pairs (the reference prints per-pair wall times,
+                                  OF.py:1073-1076, 1156-1157); a pair re-solved by a fallback carries the sum of its shares */
+    int32_t batch_pairs;       /* pairs in that batch */
+    int32_t reserved;          /* 0 */
 } vof_pair_stats;
 
 /* Kernel classes for the built-in HIP-event profiler (vof_profile_*). */
@@ -142,8 +148,12 @@ int vof_create(vof_ctx** out, int device_id, int n_i, int n_j, int max_pairs_in_
 void vof_destroy(vof_ctx* ctx);
 const char* vof_last_error(const vof_ctx* ctx); /* ctx may be NULL: error of the last failed vof_create */
 size_t vof_workspace_bytes(const vof_ctx* ctx);
-/* Device bytes a context for (n_i, n_j, max_pairs_in_flight) allocates (without host-API staging). */
+/* Device bytes a context for (n_i, n_j, max_pairs_in_flight) allocates (without host-API staging) when it is used with the
+ * default storage formats; _for: with the given vof_params.coarse_precision / vcycle_precision (the stencil storage of the
+ * stored levels is sized by the format in use: 120 / 180 / 324 / 648 bytes per coarse point; a context re-allocates it,
+ * never shrinking, when a call asks for a wider format than any call before). */
 size_t vof_query_workspace(int n_i, int n_j, int max_pairs_in_flight);
+size_t vof_query_workspace_for(int n_i, int n_j, int max_pairs_in_flight, int coarse_precision, int vcycle_precision);
 /* Free / total device memory in bytes; returns 0 on success. */
 int vof_device_memory(int device_id, size_t* free_bytes, size_t* total_bytes);
 int vof_num_levels(const vof_ctx* ctx);

@@ -33,12 +33,14 @@ class VofParams(C.Structure):
 class VofPairStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("relative_residual", C.c_double),
                 ("L1_functional", C.c_double), ("speed_functional", C.c_double),
-                ("remodelling_functional", C.c_double)]
+                ("remodelling_functional", C.c_double), ("batch_ms", C.c_double), ("batch_pairs", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 STATS_DTYPE = np.dtype([("iterations", np.int32), ("converged", np.int32), ("relative_residual", np.float64),
                         ("L1_functional", np.float64), ("speed_functional", np.float64),
-                        ("remodelling_functional", np.float64)])
+                        ("remodelling_functional", np.float64), ("batch_ms", np.float64), ("batch_pairs", np.int32),
+                        ("reserved", np.int32)])
 assert STATS_DTYPE.itemsize == C.sizeof(VofPairStats)
 
 VARIATION_DTYPE = np.dtype([("speed_mean", np.float64), ("speed_variance", np.float64), ("remodelling_mean", np.float64),
@@ -61,6 +63,7 @@ SIGNATURES = {
     "vof_last_error": (C.c_char_p, [_vp]),
     "vof_workspace_bytes": (C.c_size_t, [_vp]),
     "vof_query_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vof_query_workspace_for": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vof_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "vof_num_levels": (C.c_int, [_vp]),
     "vof_solve_stack_host": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(VofParams), _vp, _vp, _vp, _vp, _vp]),
@@ -438,8 +441,13 @@ class Solver:
         return e
 
 
-def query_workspace(n_i, n_j, pairs):
-    return int(load_library().vof_query_workspace(int(n_i), int(n_j), int(pairs)))
+def query_workspace(n_i, n_j, pairs, coarse_precision=None, vcycle_precision=None):
+    """Device bytes of a context for ``pairs`` frame pairs in flight; the stencil storage depends on the format in use
+    (``coarse_precision`` 0..3, default: the library's default format)."""
+    if coarse_precision is None and vcycle_precision is None:
+        return int(load_library().vof_query_workspace(int(n_i), int(n_j), int(pairs)))
+    return int(load_library().vof_query_workspace_for(int(n_i), int(n_j), int(pairs), 3 if coarse_precision is None else int(coarse_precision),
+                                                      3 if vcycle_precision is None else int(vcycle_precision)))
 
 
 def device_memory(device=0):

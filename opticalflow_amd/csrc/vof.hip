@@ -90,6 +90,7 @@ struct vof_ctx {
     PairScalars* h_sc = nullptr;
     double* h_func3 = nullptr;
     char* h_bounce = nullptr;        // pinned bounce buffer of the debug / test entry points (lazy)
+    hipEvent_t ev_batch[2] = {nullptr, nullptr};   // start / end of the batch in flight (vof_pair_stats.batch_ms)
     // staging for the host-pointer API (allocated lazily)
     double* st_movie = nullptr;
     double* st_out[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -107,7 +108,9 @@ struct vof_ctx {
     int* gm_cycle = nullptr;
     int gm_m = 0;
     long long gmres_pairs = 0;   // pairs handed to the fallback since the context was created
-    std::vector<void*> allocs;
+    struct Alloc { void* raw; char* user; size_t bytes; const char* name; int line; };
+    std::vector<Alloc> allocs;     // every device buffer of the context (raw != user only with guard regions)
+    int c_bytes_per_point = 0;     // stencil storage allocated per point of a stored level (120 float8 .. 648 float64)
     size_t bytes = 0;
     std::string err;
     // state of the last setup
@@ -160,6 +163,9 @@ struct vof_ctx {
     double prof_bytes[VOF_K_COUNT][16];
     double prof_moved[VOF_K_COUNT][16];
     int cur_units = 0;  // frame pairs the next launches process (active pairs of the batch)
+    // experiment (VOF_PRECOND_QUIRKS=hs, two digits): does the PRECONDITIONER see the reference's 'dy' == 'dx' quirk (OF.py:698-699)
+    // in its Galerkin hierarchy (h) / in its level-0 smoother and residual (s)?  The Krylov product always does.
+    bool pq_hier = true, pq_smooth = true;
     // fault attribution (see the "debug switches" paragraph of include/vof.h)
     int dbg_sync = 0;            // VOF_DEBUG_SYNC=1: synchronise + check after every launch scope; the first failure names its kernel class
     long long dbg_seq = 0;       // launch scopes checked so far
@@ -168,8 +174,6 @@ struct vof_ctx {
     bool dbg_canary = false;     // VOF_DEBUG_CANARY=1: every device buffer sits between two guard pages of a known pattern
     bool dbg_alloc_log = false;  // VOF_DEBUG_ALLOC_LOG=1: base / size / name of every device buffer on stderr
     bool dbg_poison = false;     // VOF_DEBUG_POISON=1: every new device buffer is filled with 0xFF bytes (NaN as float / double, -1 as int)
-    struct DbgAlloc { void* raw; char* user; size_t bytes; const char* name; int line; };
-    std::vector<DbgAlloc> dbg_allocs;
 };
 
 static std::string g_create_error;
@@ -272,12 +276,11 @@ int dev_alloc_named(vof_ctx* c, T** p, size_t n, const char* name, int line) {
         HIPCHK(hipMalloc(&q, bytes + 2 * DBG_GUARD));
         HIPCHK(hipMemset(q, DBG_GUARD_BYTE, DBG_GUARD));
         HIPCHK(hipMemset((char*)q + DBG_GUARD + bytes, DBG_GUARD_BYTE, DBG_GUARD));
-        c->allocs.push_back(q);
-        c->dbg_allocs.push_back({q, (char*)q + DBG_GUARD, bytes, name, line});
+        c->allocs.push_back({q, (char*)q + DBG_GUARD, bytes, name, line});
         *p = (T*)((char*)q + DBG_GUARD);
     } else {
         HIPCHK(hipMalloc(&q, bytes));
-        c->allocs.push_back(q);
+        c->allocs.push_back({q, (char*)q, bytes, name, line});
         *p = (T*)q;
     }
     c->bytes += bytes;
@@ -288,11 +291,62 @@ int dev_alloc_named(vof_ctx* c, T** p, size_t n, const char* name, int line) {
 }
 #define dev_alloc(c, p, n) dev_alloc_named(c, p, n, #p, __LINE__)
 
+// Releases one buffer of the context (a buffer that is re-allocated larger); nullptr is fine.
+int dev_free(vof_ctx* c, void* user) {
+    if (!user) return 0;
+    for (size_t i = 0; i < c->allocs.size(); ++i)
+        if ((void*)c->allocs[i].user == user) {
+            HIPCHK(hipFree(c->allocs[i].raw));
+            c->bytes -= c->allocs[i].bytes;
+            c->allocs.erase(c->allocs.begin() + (long)i);
+            return 0;
+        }
+    c->err = "internal: dev_free of a pointer the context does not own";
+    return -1;
+}
+
+constexpr int DEFAULT_COARSE_PRECISION = 3;
+inline int vof_params_default_coarse_precision() { return DEFAULT_COARSE_PRECISION; }
+// bytes of stencil storage per point of a stored level in format `fmt` (vof_params.coarse_precision)
+inline int coef_bytes_per_point(int fmt) { return fmt == 3 ? 30 * 4 : (fmt == 2 ? 45 * 4 : (fmt == 1 ? 81 * 4 : 81 * 8)); }
+
+// Stencil storage of the levels >= 1 for format `fmt`: allocated for the default format by vof_create, re-allocated
+// (never shrunk) when a call asks for a wider one.  Round 2 sized it for float64 whatever the format: 648 instead of 120
+// bytes per coarse point, 45 % of the workspace never touched.
+int ensure_stencil_storage(vof_ctx* c, int fmt) {
+    const int need = coef_bytes_per_point(fmt);
+    if (need <= c->c_bytes_per_point || c->L.size() < 2) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t l = 1; l < c->L.size(); ++l) {
+        Level& lv = c->L[l];
+        if (int rc = dev_free(c, lv.C)) return rc;
+        lv.C = nullptr;
+    }
+    for (size_t l = 1; l < c->L.size(); ++l) {
+        Level& lv = c->L[l];
+        uint32_t* C = nullptr;
+        if (int rc = dev_alloc(c, &C, (size_t)c->B * (need / 4) * CLay(lv.ni, lv.nj).plane)) return rc;
+        lv.C = C;
+    }
+    c->c_bytes_per_point = need;
+    c->frames = nullptr;   // a hierarchy built earlier is gone: the debug entry points ask for a new vof_debug_setup
+    return 0;
+}
+
+// Buffers that depend on the parameters of the call (every entry point runs this through check_params).
+int ensure_storage(vof_ctx* c) {
+    if (int rc = ensure_stencil_storage(c, c->prm.coarse_precision)) return rc;
+    if (c->vfloat && !c->b32)   // float32 copy of the cycle's right-hand side (vcycle_precision 1 / 2 only)
+        if (int rc = dev_alloc(c, &c->b32, (size_t)c->B * 3 * c->L[0].npts)) return rc;
+    return 0;
+}
+
 // Guard pages of every buffer of the context against their pattern; the number of damaged buffers, each named in `report`.
 int dbg_check_canaries(vof_ctx* c, std::string* report) {
     int bad = 0;
     std::vector<unsigned char> h(2 * DBG_GUARD);
-    for (const auto& a : c->dbg_allocs) {
+    if (!c->dbg_canary) return 0;
+    for (const auto& a : c->allocs) {
         if (hipMemcpy(h.data(), a.raw, DBG_GUARD, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(h.data() + DBG_GUARD, a.user + a.bytes, DBG_GUARD, hipMemcpyDeviceToHost) != hipSuccess) {
             if (report) *report += "guard pages unreadable; ";
@@ -473,7 +527,7 @@ void resrestrict_fine_t(vof_ctx* c, const VT* x, const VT* b, CVT* bc, int np, c
     Prof p(c, VOF_K_APPLY0, 0, (8.0 + 6.0 * sizeof(VT)) * f.npts + 3.0 * sizeof(CVT) * k.npts);
     k_stream_resrestrict0<VT, VT, CVT><<<g, AP_THREADS, 0, c->stream>>>(
         c->frames, frame_stride(c), c->Nj, f.ni, f.nj, TI, c->prm.speed_alpha, c->prm.remodelling_alpha,
-        c->prm.reference_quirks, x, b, bc, k.ni, k.nj, active, c->pp);
+        c->prm.reference_quirks && c->pq_smooth, x, b, bc, k.ni, k.nj, active, c->pp);
 }
 
 // stored level l >= 1, straight after ONE forward Gauss-Seidel sweep x_old -> x_new (x_old == nullptr: from zero): the coarse
@@ -559,7 +613,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 c->trail_done = true;
             }
             Prof p(c, VOF_K_GS0, 0, algo, moved);
-            Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, c->prm.reference_quirks, c->pp};
+            Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, c->prm.reference_quirks && c->pq_smooth, c->pp};
             const size_t lds = (size_t)(6 * NSW + 2 + (trail ? 4 : 0)) * s0_row_bytes(8) + (ecoarse ? (size_t)9 * (S0_W / 2 + 2) * 8 : 0);
 #define VOF_LAUNCH_S0M(NS_)                                                                                                        \
             do {                                                                                                                    \
@@ -589,7 +643,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         Prof p(c, VOF_K_GS0, 0, (8.0 + (x_in ? 9.0 : 6.0) * vs) * lv.npts + ebytes);   // I + b(3) + x(3) in, x(3) out (+ coarse e)
         SweepFine pol;
         pol.frames = c->frames; pol.frame_stride = frame_stride(c); pol.Nj = c->Nj;
-        pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks;
+        pol.alpha = c->prm.speed_alpha; pol.beta = c->prm.remodelling_alpha; pol.quirks = c->prm.reference_quirks && c->pq_smooth;
         pol.pp = c->pp;
         size_t lds = (size_t)(SW_RING * 3 * W) * sizeof(VT) + (size_t)(SW_RING * IW) * sizeof(double) +
                      (ecoarse ? (size_t)(3 * 3 * (W / 2 + 2)) * sizeof(VT) : 0);
@@ -841,7 +895,7 @@ int build_hierarchy(vof_ctx* c, int np) {
         if (l == 0) {
             Prof p(c, VOF_K_GALERKIN0, 0);
             CDISPATCH(c, 1, (k_galerkin<double, CT, true><<<g, blk2d, 0, c->stream>>>(
-                                 c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks,
+                                 c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha, P.reference_quirks && c->pq_hier,
                                  nullptr, f.ni, f.nj, (CW*)k.C, k.ni, k.nj, c->pp)));
         } else {
             Prof p(c, VOF_K_GALERKIN, l);
@@ -1056,13 +1110,22 @@ struct RocSolverApi {
             lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
-        if (!lib) { err = std::string("cannot load rocSOLVER: ") + (dlerror() ? dlerror() : "not found"); return false; }
+        if (!lib) {
+            const char* e = dlerror();   // (one call: dlerror() clears the message it returns)
+            err = std::string("cannot load rocSOLVER: ") + (e ? e : "not found");
+            return false;
+        }
         create_handle = (int (*)(void**))dlsym(lib, "rocblas_create_handle");
         destroy_handle = (int (*)(void*))dlsym(lib, "rocblas_destroy_handle");
         set_stream = (int (*)(void*, hipStream_t))dlsym(lib, "rocblas_set_stream");
         getrf = (int (*)(void*, int, int, double*, int, long long, int*, long long, int*, int))dlsym(lib, "rocsolver_dgetrf_strided_batched");
         getri = (int (*)(void*, int, double*, int, long long, int*, long long, int*, int))dlsym(lib, "rocsolver_dgetri_strided_batched");
-        if (!create_handle || !destroy_handle || !set_stream || !getrf || !getri) { err = "rocSOLVER / rocBLAS symbols missing"; lib = nullptr; return false; }
+        if (!create_handle || !destroy_handle || !set_stream || !getrf || !getri) {
+            err = "rocSOLVER / rocBLAS symbols missing";
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
         return true;
     }
 };
@@ -1189,6 +1252,7 @@ int direct_apply_t(vof_ctx* c, VT* z, const VT* r, int np) {
 int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double* vy, double* gm, double* speed,
                 vof_pair_stats* stats) {
     const vof_params& P = c->prm;
+    if (stats) HIPCHK(hipEventRecord(c->ev_batch[0], c->stream));
     // storage type of the cycle vectors for this batch (an earlier batch may have switched to float64: "auto"
     // precision after 8 iterations, GMRES fallback)
     c->vfloat = (P.vcycle_precision == 1 || P.vcycle_precision == 2) && c->fused && c->L.size() > 1 && !c->direct_on;
@@ -1348,7 +1412,10 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     if (stats) {
         HIPCHK(hipMemcpyAsync(c->h_sc, c->sc, np * sizeof(PairScalars), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(c->h_func3, c->func3, np * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(c->ev_batch[1], s));
         HIPCHK(hipStreamSynchronize(s));
+        float batch_ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&batch_ms, c->ev_batch[0], c->ev_batch[1]));
         for (int k = 0; k < np; ++k) {
             const PairScalars& q = c->h_sc[k];
             stats[k].iterations = q.iterations;
@@ -1357,6 +1424,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
             stats[k].L1_functional = c->h_func3[3 * k];
             stats[k].speed_functional = c->h_func3[3 * k + 1];
             stats[k].remodelling_functional = c->h_func3[3 * k + 2];
+            stats[k].batch_ms = batch_ms;
+            stats[k].batch_pairs = np;
+            stats[k].reserved = 0;
         }
     }
     return 0;
@@ -1389,7 +1459,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     // float32 V-cycle vectors need the fused sweeps and a multi-level hierarchy
     c->vfloat = (p->vcycle_precision == 1 || p->vcycle_precision == 2) && c->fused && c->L.size() > 1;
     c->vcoarse32 = false;   // set per batch (solve_batch); the debug entry points run every level in one storage type
-    return 0;
+    return ensure_storage(c);
 }
 
 }  // namespace
@@ -1436,22 +1506,27 @@ const char* vof_last_error(const vof_ctx* ctx) { return ctx ? ctx->err.c_str() :
 size_t vof_workspace_bytes(const vof_ctx* ctx) { return ctx ? ctx->bytes : 0; }
 int vof_num_levels(const vof_ctx* ctx) { return ctx ? (int)ctx->L.size() : 0; }
 
-size_t vof_query_workspace(int n_i, int n_j, int B) {
-    if (n_i < 4 || n_j < 4 || B < 1) return 0;
+size_t vof_query_workspace(int n_i, int n_j, int B) { return vof_query_workspace_for(n_i, n_j, B, DEFAULT_COARSE_PRECISION, 3); }
+
+size_t vof_query_workspace_for(int n_i, int n_j, int B, int coarse_precision, int vcycle_precision) {
+    if (n_i < 4 || n_j < 4 || B < 1 || coarse_precision < 0 || coarse_precision > 3) return 0;
     size_t ni = n_i - 2, nj = n_j - 2, total = 0, b = (size_t)B;
     std::vector<std::pair<size_t, size_t>> lv{{ni, nj}};
     while (std::max(lv.back().first, lv.back().second) > (size_t)coarsest_max())
         lv.push_back({(lv.back().first + 1) / 2, (lv.back().second + 1) / 2});
-    total += 10 * b * 3 * ni * nj;
+    size_t words = 0;   // 32-bit words of stencil storage
+    total += (9 + ((vcycle_precision == 1 || vcycle_precision == 2) && lv.size() > 1 ? 1 : 0)) * b * 3 * ni * nj;
     for (size_t l = 0; l < lv.size(); ++l) {
         size_t npts = lv[l].first * lv[l].second;
-        if (l + 1 < lv.size()) total += 2 * b * 3 * npts;
+        if (l + 1 < lv.size()) total += (l > 0 ? 2 : 1) * b * 3 * npts;
         if (l > 0) total += 2 * b * 3 * npts;
-        if (l > 0 || lv.size() == 1) total += b * 81 * CLay((int)lv[l].first, (int)lv[l].second).plane;
+        const size_t plane = CLay((int)lv[l].first, (int)lv[l].second).plane;
+        if (lv.size() == 1) total += b * 81 * plane;
+        else if (l > 0) words += b * (size_t)(coef_bytes_per_point(coarse_precision) / 4) * plane;
     }
     size_t nd = 3 * lv.back().first * lv.back().second;
     total += b * nd * 2 * nd + b * nd * nd;
-    return total * sizeof(double) + (size_t)B * 3 * 256 * sizeof(double) + 4096;
+    return total * sizeof(double) + words * 4 + (size_t)B * 3 * 256 * sizeof(double) + 4096;
 }
 
 int vof_device_memory(int device_id, size_t* free_bytes, size_t* total_bytes) {
@@ -1485,11 +1560,12 @@ void vof_destroy(vof_ctx* c) {
     if (c->dbg_fd >= 0) close(c->dbg_fd);
     prof_collect(c);
     for (auto e : c->free_events) hipEventDestroy(e);
-    for (void* p : c->allocs) hipFree(p);
+    for (const auto& a : c->allocs) hipFree(a.raw);
     if (c->h_active) hipHostFree(c->h_active);
     if (c->h_sc) hipHostFree(c->h_sc);
     if (c->h_func3) hipHostFree(c->h_func3);
     if (c->h_bounce) hipHostFree(c->h_bounce);
+    for (int i = 0; i < 2; ++i) if (c->ev_batch[i]) hipEventDestroy(c->ev_batch[i]);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_solved[i]) hipEventDestroy(c->ev_solved[i]);
         if (c->ev_copied[i]) hipEventDestroy(c->ev_copied[i]);
@@ -1523,6 +1599,8 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_DEBUG_POISON")) c->dbg_poison = e[0] != '0';
     if (c->dbg_sync)
         if (const char* e = getenv("VOF_DEBUG_SYNC_FILE")) c->dbg_fd = open(e, O_WRONLY | O_CREAT, 0644);
+    if (const char* e = getenv("VOF_PRECOND_QUIRKS")) { c->pq_hier = e[0] != '0'; c->pq_smooth = e[0] && e[1] != '0'; }
+    if (!c->pq_smooth) c->trail_enabled = false;   // the fused Krylov product shares the smoother's operator
     if (const char* e = getenv("VOF_SWEEP_GEO")) {   // experiment switch: "AA", "AB" (default), "BA", "BB" = fine,stored
         c->geo_b_fine = e[0] == 'B';
         c->geo_b_stored = e[0] && e[1] == 'B';
@@ -1548,23 +1626,27 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     int nl = (int)c->L.size();
     if (nl > 16) { c->err = "too many levels"; return -1; }
     size_t len0 = 3 * l0.npts;
-    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky, &c->kz, &c->b32})
+    // (b32, the float32 copy of the cycle's right-hand side, exists only while vcycle_precision 1 / 2 is in use: ensure_storage)
+    for (double** v : {&c->kx, &c->kb, &c->kr, &c->krh, &c->kp, &c->kv, &c->kt, &c->ky, &c->kz})
         if (int rc = dev_alloc(c, v, (size_t)B * len0)) return rc;
     for (int l = 0; l < nl; ++l) {
         Level& lv = c->L[l];
         auto valloc = [&](void** q) { double* t = nullptr; int rc = dev_alloc(c, &t, (size_t)B * 3 * lv.npts); *q = t; return rc; };
-        if (l + 1 < nl) if (int rc = valloc(&lv.r)) return rc;
+        // residual scratch: level 0 needs it only with the stand-alone residual + restriction kernels (experiment switches)
+        if (l + 1 < nl && (l > 0 || !(c->stream_apply && c->fuse_restrict))) if (int rc = valloc(&lv.r)) return rc;
         if (l + 1 < nl) if (int rc = valloc(&lv.x2)) return rc;
         if (l > 0) {
             if (int rc = valloc(&lv.x)) return rc;
             if (int rc = valloc(&lv.b)) return rc;
         }
-        if (l > 0 || nl == 1) {
+        if (nl == 1) {   // a one-level grid keeps its fine stencil as float64
             double* C = nullptr;
             if (int rc = dev_alloc(c, &C, (size_t)B * 81 * CLay(lv.ni, lv.nj).plane)) return rc;
             lv.C = C;
         }
     }
+    // stored stencils of the levels >= 1: sized for the default format; a call that asks for a wider one re-allocates them
+    if (int rc = ensure_stencil_storage(c, vof_params_default_coarse_precision())) return rc;
     c->nd = 3 * (int)c->L.back().npts;
     {   // coarse tail: the deepest run of levels that fit one workgroup (and its LDS)
         int first = -1;
@@ -1623,6 +1705,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     HIPCHK(hipHostMalloc((void**)&c->h_active, B * sizeof(int)));
     HIPCHK(hipHostMalloc((void**)&c->h_sc, B * sizeof(PairScalars)));
     HIPCHK(hipHostMalloc((void**)&c->h_func3, B * 3 * sizeof(double)));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreate(&c->ev_batch[i]));
     return 0;
 }
 
@@ -1656,6 +1739,8 @@ static int solve_stack_two_phase(vof_ctx* c, const double* movie, int P, double*
     if (!c->pp_buf) { if (int rc = dev_alloc(c, &c->pp_buf, (size_t)B)) return rc; }
     if (!c->warm_src) { if (int rc = dev_alloc(c, &c->warm_src, (size_t)B)) return rc; }
     if (c->warm_cap < (size_t)n1 * len) {
+        if (int rc = dev_free(c, c->warm_x)) return rc;   // (round 2 kept every outgrown buffer until vof_destroy)
+        c->warm_x = nullptr; c->warm_cap = 0;
         if (int rc = dev_alloc(c, &c->warm_x, (size_t)n1 * len)) return rc;
         c->warm_cap = (size_t)n1 * len;
     }
@@ -1768,6 +1853,7 @@ static int solve_range_dev(vof_ctx* c, const double* frames, int P, double* v_x,
             } else {
                 for (size_t i = 0; i < which.size(); ++i) {
                     st[i].iterations += stats[which[i]].iterations;   // Krylov steps of both attempts
+                    st[i].batch_ms += stats[which[i]].batch_ms / std::max(1, stats[which[i]].batch_pairs) * st[i].batch_pairs;   // and their time (per-pair share kept)
                     stats[which[i]] = st[i];
                 }
             }

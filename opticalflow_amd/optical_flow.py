@@ -126,11 +126,13 @@ def apply_constant_boundary_condition(image):
     image[:, -1] = image[:, -3]
 
 
-def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=128):
-    """Largest batch of frame pairs whose workspace fits in ``memory_fraction`` of the free HBM."""
+def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap=128, params=None, staging=True):
+    """Largest batch of frame pairs whose workspace fits in ``memory_fraction`` of the free HBM (``params``: the solver
+    parameters of the call - the stencil storage is sized by their ``coarse_precision``)."""
     free, _total = _native.device_memory(device)
     budget = free * memory_fraction
-    per_pair = _native.query_workspace(n_i, n_j, 1) + 9 * n_i * n_j * 8  # + host-API staging (two output sets)
+    fmt = (None, None) if params is None else (int(params.coarse_precision), int(params.vcycle_precision))
+    per_pair = _native.query_workspace(n_i, n_j, 1, *fmt) + (9 * n_i * n_j * 8 if staging else 0)  # + host-API staging (two output sets)
     return int(max(1, min(n_pairs, cap, budget // max(per_pair, 1))))
 
 
@@ -292,7 +294,7 @@ def variational_optical_flow(movie,
                             multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart, warm_start_stride, preconditioner)
     exact = max_pairs_in_flight is not None
     if max_pairs_in_flight is None and _solver is None:
-        max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device)
+        max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device, params=params)
     t0 = time.time()
     # a caller-owned context (_solver) or the module's cached one; blur and solve share it
     with (contextlib.nullcontext(_solver) if _solver is not None
@@ -350,7 +352,8 @@ def _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_i
         raise ValueError("movie needs at least two frames")
     exact = max_pairs_in_flight is not None
     if max_pairs_in_flight is None:
-        max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, int(device))
+        # device-resident call: no staging buffers, and what is free now is free of the caller's tensors already
+        max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, int(device), memory_fraction=0.8, params=params, staging=False)
     out = [torch.empty((T - 1, N_i, N_j), dtype=torch.float64, device=dev) for _ in range(4)]
     torch.cuda.synchronize(dev)          # the library launches on its own stream
     with _device_context(N_i, N_j, max_pairs_in_flight, device, exact) as solver:
@@ -423,7 +426,7 @@ def vary_regularisation(movie,
     taps = None if kw["smoothing_sigma"] is None else gaussian_taps(kw["smoothing_sigma"])
     # short movies: several combinations share one batch as "virtual pairs" (see vof_vary_regularisation_host)
     n_comb = max(1, len(speed_alpha_values) * len(remodelling_alpha_values))
-    pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, (T - 1) * n_comb, kw["device"])
+    pairs = kw["max_pairs_in_flight"] or choose_pairs_in_flight(N_i, N_j, (T - 1) * n_comb, kw["device"], params=params)
     with _device_context(N_i, N_j, pairs, kw["device"], kw["max_pairs_in_flight"] is not None) as solver:
         try:
             rec = solver.vary_regularisation_host(movie.astype(np.float64), params, speed_alpha_values,

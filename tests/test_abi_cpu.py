@@ -35,14 +35,14 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_version_and_default_params(lib):
     from opticalflow_amd import _native
-    assert lib.vof_version() == 201
+    assert lib.vof_version() == 202
     p = _native.default_params()
     # the reference's solver settings: OF.py:718-719, 1120
     assert (p.speed_alpha, p.remodelling_alpha, p.rtol, p.max_iterations) == (1.0, 1000.0, 1e-6, 1000)
     assert (p.nu_pre, p.nu_post, p.nu_pre_coarse, p.nu_post_coarse, p.w_cycle_level, p.w_cycle_visits) == (2, 2, 1, 1, 1, 3)
     assert (p.reference_quirks, p.coarse_precision, p.vcycle_precision) == (1, 3, 3)
     assert C.sizeof(_native.VofParams) == 2 * 4 + 8 * 8 + 16 * 4 == lib.vof_params_size()
-    assert C.sizeof(_native.VofPairStats) == 40
+    assert C.sizeof(_native.VofPairStats) == 56
     with pytest.raises(TypeError):
         _native.default_params(no_such_field=1)
 
@@ -50,9 +50,17 @@ def test_version_and_default_params(lib):
 def test_workspace_query(lib):
     from opticalflow_amd import _native
     one = _native.query_workspace(1024, 1024, 1)
-    assert 3e8 < one < 7e8                       # ~0.48 GB per 1024^2 pair
+    assert 2.5e8 < one < 3.4e8                   # 0.32 GB per 1024^2 pair with the default formats (round 2: 0.50)
     assert abs(_native.query_workspace(1024, 1024, 8) / one - 8) < 0.01
     assert _native.query_workspace(3, 3, 1) == 0  # invalid size
+    # the stencil storage follows the format: 120 / 180 / 324 / 648 bytes per coarse point (1/3 of a fine point's share)
+    by_fmt = [_native.query_workspace(1024, 1024, 1, f, 3) for f in (3, 2, 1, 0)]
+    assert by_fmt[0] == one and by_fmt == sorted(by_fmt)
+    third = 1022 * 1022 / 3.0
+    for got, want in zip([b - by_fmt[0] for b in by_fmt[1:]], [60, 204, 528]):
+        assert abs(got / third - want) < 0.05 * want
+    # float32 cycle vectors on every level (vcycle_precision 1 / 2) keep one more level-0 vector
+    assert _native.query_workspace(1024, 1024, 1, 3, 1) - one == pytest.approx(3 * 1022 * 1022 * 8, rel=1e-6)
 
 
 def test_kernel_names(lib):

@@ -35,6 +35,9 @@ def check(d, n_gpus):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert r["achieved"] > 0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    # an HBM fraction: bytes the launch has to move over its time (the per-sweep work rate is reported separately)
+    assert r["achieved"] == pytest.approx(r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9)
+    assert r["frac"] < 1 and r["effective_per_sweep"]["rate"] >= r["achieved"] * 0.999
 
 
 def test_single_gpu_line_with_cpu_baseline():
@@ -46,7 +49,7 @@ def test_single_gpu_line_with_cpu_baseline():
     e = d["end_to_end"]
     assert e["unit"] == "frame-pairs/s" and 0 < e["value"] and e["converged"] is True
     w = d["roofline"]["whole_solve"]
-    assert 0 < w["frac"] < 1 and w["algorithmic_bytes_per_step"] > 0
+    assert 0 < w["frac"] < 1 and w["bytes_per_step"] > 0 and w["frac"] == pytest.approx(w["achieved"] / 8000.0)
     assert d["value"] / c["value"] > 10                # sanity only: the ratio says nothing about kernel quality
 
 

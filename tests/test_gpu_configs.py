@@ -97,8 +97,10 @@ def test_config5_share_of_one_gpu_2048x2048x17(of):
 
 
 def test_config5_2048x2048x128_on_one_gpu(of):
-    """C5 on a single GPU: 127 pairs of 2048x2048 in two batches, two-phase warm start inside the stack."""
+    """C5 on a single GPU: all 127 pairs of 2048x2048 in ONE batch (the stencil storage is sized by the 8-bit format:
+    1.3 GB per pair in flight; round 2 needed two batches), two-phase warm start inside the stack."""
     _solve_and_check(of, 2048, 128, seed=3, first_frame=0, stride=None, sample=(0, 1, 100, 126))
+    assert of._cache["solver"].max_pairs == 127
 
 
 @pytest.mark.parametrize("n", [64, 512, 1024])

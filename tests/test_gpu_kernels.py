@@ -61,6 +61,28 @@ def test_rhs_operator_smoother(native, kind, shape, npairs, alpha, beta, seed, q
                 assert relerr(xg, xr) < 1e-11, colour
 
 
+def test_stencil_storage_follows_the_format_in_use(native):
+    """The stencil storage of the stored levels is sized by the format (120 / 180 / 324 / 648 bytes per coarse point): a
+    context starts with the default format's, grows when a call asks for a wider one (never shrinks), reports it through
+    vof_workspace_bytes == vof_query_workspace_for, and the hierarchy is right after every re-allocation."""
+    kind, shape, npairs, alpha, beta, seed = CASES[2]
+    mv = make_case(kind, shape, npairs, seed)
+    H = [mg.Hierarchy(mv[k], alpha, beta) for k in range(npairs)]
+    tol = {0: 1e-12, 1: 2e-6, 2: 4e-3, 3: 6e-2}
+    with native.Solver(shape[0], shape[1], npairs) as s:
+        widest = 3
+        assert s.workspace_bytes == pytest.approx(native.query_workspace(shape[0], shape[1], npairs), rel=1e-2)   # small grids: the fixed-size buffers count
+        for fmt in (3, 2, 3, 0, 1, 3):
+            s.debug_setup(mv, native.default_params(speed_alpha=alpha, remodelling_alpha=beta, coarse_precision=fmt))
+            widest = min(widest, fmt)
+            staging = (npairs + 1 + 4 * npairs) * shape[0] * shape[1] * 8          # vof_debug_setup uploads through the host-API staging
+            assert s.workspace_bytes - staging == pytest.approx(native.query_workspace(shape[0], shape[1], npairs, widest, 3), rel=1e-2)
+            for lvl in range(1, s.num_levels):
+                Cg = s.debug_stencil(lvl)
+                for k in range(npairs):
+                    assert relerr(Cg[k], H[k].levels[lvl]) < tol[fmt], (fmt, lvl)
+
+
 @pytest.mark.parametrize("kind,shape,npairs,alpha,beta,seed", CASES[1:])
 @pytest.mark.parametrize("coarse_precision", [0, 1, 2, 3])
 def test_galerkin_hierarchy_and_transfers(native, kind, shape, npairs, alpha, beta, seed, coarse_precision):
