@@ -7,6 +7,7 @@
 // operators; stopping rule ||b - A x|| <= rtol ||b|| (OF.py:1120,1126).  All frame pairs of a batch
 // advance together; per-pair scalars stay on the device.
 #include "vof_device.hpp"
+#include "vof_sweep0r.hpp"
 #include "vof_direct.hpp"
 #include "../../include/vof.h"
 
@@ -146,6 +147,7 @@ struct vof_ctx {
     int trail_nblk = 0;         // per-pair partial sums the fused pass wrote
     bool sweep0m = true;        // level 0, float64 vectors, even n_j: k_sweep0m (VOF_SWEEP0M=0: k_sweep0)
     bool sweep0m_pairs = true;  // ... two sweeps per pass (VOF_SWEEP0M=1: one sweep per pass)
+    bool sweep0r = true;        // ... the register-resident pass k_sweep0r (VOF_SWEEP0R=0: the LDS-ring pass k_sweep0m)
     bool tail_enabled = true;   // fused LDS-resident coarse-tail kernel (VOF_COARSE_TAIL=0: one launch per operation)
     int tail_first = -1;        // first level of the tail (-1: no tail for this grid)
     size_t tail_lds = 0;        // dynamic LDS bytes of k_tail_cycle
@@ -625,7 +627,23 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (!x_in) k_sweep0m<NS_, false, true, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0m<NS_, false, false, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
-            if (NSW == 2) VOF_LAUNCH_S0M(2); else VOF_LAUNCH_S0M(1);
+#define VOF_LAUNCH_S0R(NS_, PO_)                                                                                                   \
+            do {                                                                                                                    \
+                const size_t ldsr = trail ? S0R<NS_, 1>::LDS_BYTES : S0R<NS_, 0>::LDS_BYTES;                                       \
+                if (trail && ecoarse && ec32) k_sweep0r<NS_, true, false, 1, float, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr); \
+                else if (ecoarse && ec32) k_sweep0r<NS_, true, false, 0, float, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr); \
+                else if (trail && ecoarse) k_sweep0r<NS_, true, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (trail) k_sweep0r<NS_, false, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (ecoarse) k_sweep0r<NS_, true, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else k_sweep0r<NS_, false, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+            } while (0)
+            if (c->sweep0r) {
+                if (NSW == 2) { if (po) VOF_LAUNCH_S0R(2, 1); else VOF_LAUNCH_S0R(2, 0); }
+                else { if (po) VOF_LAUNCH_S0R(1, 1); else VOF_LAUNCH_S0R(1, 0); }
+            }
+            else if (NSW == 2) VOF_LAUNCH_S0M(2); else VOF_LAUNCH_S0M(1);
+#undef VOF_LAUNCH_S0R
 #undef VOF_LAUNCH_S0M
             return;
         }
@@ -1615,6 +1633,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_COARSE_TAIL")) c->tail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0")) c->sweep0 = e[0] != '0';
     if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';
+    if (const char* e = getenv("VOF_SWEEP0R")) c->sweep0r = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0M")) { c->sweep0m = e[0] != '0'; c->sweep0m_pairs = e[0] != '0' && e[0] != '1'; }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;
