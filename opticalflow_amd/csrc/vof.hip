@@ -137,6 +137,8 @@ struct vof_ctx {
     int dir_cap = 0;                 // pairs the direct buffers hold
     double *dir_T = nullptr, *dir_tabs = nullptr, *dir_W = nullptr, *dir_r = nullptr, *dir_y = nullptr, *dir_x = nullptr, *dir_t = nullptr;
     int *dir_ipiv = nullptr, *dir_info = nullptr;
+    double *dir_R = nullptr, *dir_C = nullptr, *dir_D = nullptr;   // blocked inverse: row panel, column panel, inverted diagonal tile
+    int dir_ld = 0;                  // leading dimension of the dense blocks (m, or m rounded up to the tile size of the blocked inverse)
     void* roc_handle = nullptr;      // rocblas_handle for rocSOLVER
     long long direct_pairs = 0;      // pairs solved with the direct preconditioner since the context was created
     // Krylov product fused into the last smoothing pass of a cycle (k_sweep0m's trailing stage): requested by the Krylov loop
@@ -638,7 +640,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0r<NS_, false, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
-            if (c->sweep0r) {
+            if (c->sweep0r && f0.quirks) {   // (the register-resident pass is compiled with the reference's derivative quirk built in)
                 if (NSW == 2) { if (po) VOF_LAUNCH_S0R(2, 1); else VOF_LAUNCH_S0R(2, 0); }
                 else { if (po) VOF_LAUNCH_S0R(1, 1); else VOF_LAUNCH_S0R(1, 0); }
             }
@@ -1149,27 +1151,33 @@ struct RocSolverApi {
 };
 RocSolverApi g_roc;
 
-// Dense inverse of the Schur blocks: the built-in Gauss-Jordan kernel (one workgroup per matrix) up to DIRECT_OWN_MAX
-// unknowns per image row, rocSOLVER getrf + getri beyond (VOF_DIRECT_LU=own|rocsolver forces one).
+// Dense inverse of the Schur blocks, all in-house: the one-workgroup Gauss-Jordan kernel with partial pivoting up to
+// DIRECT_OWN_MAX unknowns per image row (the down-sampled images the reference sweeps at), the blocked Gauss-Jordan on the
+// FP64 matrix cores beyond (vof_direct.hpp).  VOF_DIRECT_LU=own|blocked|rocsolver forces one (rocSOLVER getrf + getri,
+// round 2's choice for wide images, is loaded with dlopen only when asked for: an A/B reference, not a product path).
 constexpr int DIRECT_OWN_MAX = 640;
-bool direct_uses_rocsolver(const vof_ctx* c) {
-    if (const char* e = getenv("VOF_DIRECT_LU")) return e[0] == 'r';
+bool direct_uses_rocsolver(const vof_ctx*) {
+    const char* e = getenv("VOF_DIRECT_LU");
+    return e && e[0] == 'r';
+}
+bool direct_uses_blocked(const vof_ctx* c) {
+    if (const char* e = getenv("VOF_DIRECT_LU")) return e[0] == 'b';
     return 3 * c->L[0].nj > DIRECT_OWN_MAX;
 }
-
-// The automatic re-solve (preconditioner 2) must not stall a call for minutes behind a library load nobody asked for: it
-// uses rocSOLVER only if that is resident already (or forced by VOF_DIRECT_LU); the built-in kernel is always available.
-int direct_capacity(vof_ctx* c, int want);
-bool direct_ok_for_fallback(vof_ctx* c) {
-    if (direct_capacity(c, 1) < 1) return false;
-    if (!direct_uses_rocsolver(c)) return true;
-    return getenv("VOF_DIRECT_LU") != nullptr || g_roc.resident();
+int direct_ld(const vof_ctx* c) {
+    const int m = 3 * c->L[0].nj;
+    return direct_uses_blocked(c) ? ((m + DNB - 1) / DNB) * DNB : m;
 }
+
+// The automatic re-solve (preconditioner 2) needs nothing but room for the buffers.
+int direct_capacity(vof_ctx* c, int want);
+bool direct_ok_for_fallback(vof_ctx* c) { return direct_capacity(c, 1) >= 1; }
 
 // device bytes the direct preconditioner needs per pair in flight
 size_t direct_bytes_per_pair(const vof_ctx* c) {
-    const size_t ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj;
-    return (ni * m * m + m * m + ni * nj * DIR_TAB + (3 * ni + 1) * m) * sizeof(double) + (m + 1) * sizeof(int);
+    const size_t ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj, ld = (size_t)direct_ld(c);
+    const size_t panels = direct_uses_blocked(c) ? (2 * ld + DNB) * DNB : 0;
+    return (ni * ld * ld + ld * ld + panels + ni * nj * DIR_TAB + (3 * ni + 1) * m) * sizeof(double) + (m + 1) * sizeof(int);
 }
 
 // how many pairs the direct preconditioner can hold (0: it does not fit / is not available)
@@ -1188,15 +1196,24 @@ int direct_alloc(vof_ctx* c, int pairs) {
     if (c->dir_cap >= pairs) return 0;
     if (c->dir_cap > 0) { c->err = "direct preconditioner buffers already allocated for a smaller batch"; return -3; }
     const bool trace = getenv("VOF_TRACE") != nullptr;
-    const size_t ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj, P = (size_t)pairs;
+    const size_t ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj, P = (size_t)pairs, ld = (size_t)direct_ld(c);
+    c->dir_ld = (int)ld;
     if (direct_uses_rocsolver(c)) {
         // (the library is ~0.9 GB: its first load on a machine can take minutes; the small blocks use the built-in kernel)
         if (trace) { fprintf(stderr, "[vof] direct_alloc: loading rocSOLVER\n"); fflush(stderr); }
         if (!g_roc.load()) { c->err = g_roc.err; return -3; }
         if (trace) { fprintf(stderr, "[vof] direct_alloc: rocSOLVER loaded, allocating for %d pairs\n", pairs); fflush(stderr); }
     }
-    if (int rc = dev_alloc(c, &c->dir_T, P * ni * m * m)) return rc;
-    if (int rc = dev_alloc(c, &c->dir_W, P * m * m)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_T, P * ni * ld * ld)) return rc;
+    if (int rc = dev_alloc(c, &c->dir_W, P * ld * ld)) return rc;
+    if (direct_uses_blocked(c)) {
+        if (int rc = dev_alloc(c, &c->dir_R, P * ld * DNB)) return rc;
+        if (int rc = dev_alloc(c, &c->dir_C, P * ld * DNB)) return rc;
+        if (int rc = dev_alloc(c, &c->dir_D, P * DNB * DNB)) return rc;
+        const int lds = (DNB * DNB + DNB * DNB_LDB) * (int)sizeof(double);
+        HIPCHK(hipFuncSetAttribute((const void*)k_dir_bgj_panel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_dir_bgj_update, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     if (int rc = dev_alloc(c, &c->dir_tabs, P * ni * nj * DIR_TAB)) return rc;
     if (int rc = dev_alloc(c, &c->dir_r, P * ni * m)) return rc;
     if (int rc = dev_alloc(c, &c->dir_y, P * ni * m)) return rc;
@@ -1217,20 +1234,29 @@ int direct_alloc(vof_ctx* c, int pairs) {
 // factorisation for the current batch (frames / PairParam table as set up by solve_batch)
 int direct_setup(vof_ctx* c, int np) {
     const vof_params& P = c->prm;
-    const int ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj;
-    const size_t sT = (size_t)ni * m * m, sW = (size_t)m * m, sTab = (size_t)ni * nj * DIR_TAB, rowTab = (size_t)nj * DIR_TAB;
+    const int ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj, ld = c->dir_ld;
+    const size_t sT = (size_t)ni * ld * ld, sW = (size_t)ld * ld, sTab = (size_t)ni * nj * DIR_TAB, rowTab = (size_t)nj * DIR_TAB;
     hipStream_t s = c->stream;
     Prof pr(c, VOF_K_COARSE_SETUP, 0);
+    HIPCHK(hipMemsetAsync(c->dir_info, 0, (size_t)np * sizeof(int), s));
     k_dir_tables<<<dim3((nj + 255) / 256, ni, np), 256, 0, s>>>(c->frames, frame_stride(c), c->Nj, P.speed_alpha, P.remodelling_alpha,
                                                                P.reference_quirks, ni, nj, c->dir_tabs, c->pp);
-    const dim3 gm((m + 255) / 256, m, np);
+    const dim3 gm((m + 255) / 256, m, np), gs((ld + 255) / 256, ld, np);
     const bool trace = getenv("VOF_TRACE") != nullptr;
+    const bool blocked = direct_uses_blocked(c);
+    const int nt = ld / DNB;
+    const size_t bgj_lds = (size_t)(DNB * DNB + DNB * DNB_LDB) * sizeof(double);
     for (int p = 0; p < ni; ++p) {
         if (trace && (p < 2 || p == ni - 1)) { HIPCHK(hipStreamSynchronize(s)); fprintf(stderr, "[vof] direct_setup: row %d of %d (m = %d, %d pairs)\n", p, ni, m, np); fflush(stderr); }
-        double* Tp = c->dir_T + (size_t)p * m * m;
-        if (p > 0) k_dir_W<<<gm, 256, 0, s>>>(Tp - (size_t)m * m, sT, c->dir_tabs + (size_t)(p - 1) * rowTab, sTab, nj, c->dir_W, sW);
-        k_dir_schur<<<gm, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, p > 0 ? c->dir_W : nullptr, sW, Tp, sT);
-        if (direct_uses_rocsolver(c)) {
+        double* Tp = c->dir_T + (size_t)p * ld * ld;
+        if (p > 0) k_dir_W<<<gm, 256, 0, s>>>(Tp - (size_t)ld * ld, sT, c->dir_tabs + (size_t)(p - 1) * rowTab, sTab, nj, c->dir_W, sW, ld);
+        k_dir_schur<<<gs, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, p > 0 ? c->dir_W : nullptr, sW, Tp, sT, ld);
+        if (blocked) {
+            for (int kt = 0; kt < nt; ++kt) {
+                k_dir_bgj_panel<<<dim3(nt, 2, np), 256, bgj_lds, s>>>(Tp, sT, ld, kt, c->dir_R, c->dir_C, c->dir_D, c->dir_info);
+                k_dir_bgj_update<<<dim3(nt, nt, np), 256, bgj_lds, s>>>(Tp, sT, ld, kt, c->dir_R, c->dir_C, c->dir_D);
+            }
+        } else if (direct_uses_rocsolver(c)) {
             if (g_roc.getrf(c->roc_handle, m, m, Tp, m, (long long)sT, c->dir_ipiv, (long long)m, c->dir_info, np) != 0 ||
                 g_roc.getri(c->roc_handle, m, Tp, m, (long long)sT, c->dir_ipiv, (long long)m, c->dir_info, np) != 0) {
                 c->err = "rocSOLVER getrf / getri failed";
@@ -1241,27 +1267,34 @@ int direct_setup(vof_ctx* c, int np) {
         }
     }
     HIPCHK(hipGetLastError());
+    if (!direct_uses_rocsolver(c)) {   // a singular pivot anywhere makes the preconditioner useless for that pair: report it instead of iterating on garbage
+        std::vector<int> info((size_t)np);
+        HIPCHK(hipMemcpyAsync(info.data(), c->dir_info, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int k = 0; k < np; ++k)
+            if (info[k] != 0) { c->err = "direct preconditioner: a Schur block of pair " + std::to_string(k) + " of the batch is singular"; return -2; }
+    }
     return 0;
 }
 
 // z = A^{-1} r by block forward / backward substitution (r, z: level-0 vectors of the V-cycle type)
 template <typename VT>
 int direct_apply_t(vof_ctx* c, VT* z, const VT* r, int np) {
-    const int ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj;
-    const size_t sT = (size_t)ni * m * m, sTab = (size_t)ni * nj * DIR_TAB, rowTab = (size_t)nj * DIR_TAB, sV = (size_t)ni * m;
+    const int ni = c->L[0].ni, nj = c->L[0].nj, m = 3 * nj, ld = c->dir_ld;
+    const size_t sT = (size_t)ni * ld * ld, sTab = (size_t)ni * nj * DIR_TAB, rowTab = (size_t)nj * DIR_TAB, sV = (size_t)ni * m;
     hipStream_t s = c->stream;
     Prof pr(c, VOF_K_COARSE_SOLVE, 0);
     const dim3 gp(64, np), gv((m + 255) / 256, np), gg((m + 63) / 64, np);
     k_dir_permute<const VT, true><<<gp, 256, 0, s>>>(r, c->dir_r, ni, nj);
     for (int p = 0; p < ni; ++p) {      // forward: y_p = r_p - L_p T_{p-1} y_{p-1}
-        if (p > 0) k_dir_gemv<<<gg, 256, 0, s>>>(c->dir_T + (size_t)(p - 1) * m * m, sT, m, c->dir_y + (size_t)(p - 1) * m, sV, c->dir_t, (size_t)m);
+        if (p > 0) k_dir_gemv<<<gg, 256, 0, s>>>(c->dir_T + (size_t)(p - 1) * ld * ld, sT, m, c->dir_y + (size_t)(p - 1) * m, sV, c->dir_t, (size_t)m, ld);
         k_dir_rowupdate<<<gv, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, -1, c->dir_r + (size_t)p * m, sV,
                                           p > 0 ? c->dir_t : nullptr, (size_t)m, c->dir_y + (size_t)p * m, sV);
     }
     for (int p = ni - 1; p >= 0; --p) {  // backward: x_p = T_p (y_p - U_p x_{p+1})
         k_dir_rowupdate<<<gv, 256, 0, s>>>(c->dir_tabs + (size_t)p * rowTab, sTab, nj, +1, c->dir_y + (size_t)p * m, sV,
                                           p + 1 < ni ? c->dir_x + (size_t)(p + 1) * m : nullptr, sV, c->dir_t, (size_t)m);
-        k_dir_gemv<<<gg, 256, 0, s>>>(c->dir_T + (size_t)p * m * m, sT, m, c->dir_t, (size_t)m, c->dir_x + (size_t)p * m, sV);
+        k_dir_gemv<<<gg, 256, 0, s>>>(c->dir_T + (size_t)p * ld * ld, sT, m, c->dir_t, (size_t)m, c->dir_x + (size_t)p * m, sV, ld);
     }
     k_dir_permute<VT, false><<<gp, 256, 0, s>>>(z, c->dir_x, ni, nj);
     return 0;

@@ -60,7 +60,8 @@ struct S0RRow { double2 u, w, g; };   // one x row of the strip: .x = column 2 l
 
 // PO: 0 = forward colour order 0, 1, 2, 3; 1 = reverse order (rows shifted by one, odd columns first) - a template parameter
 // so that the column parity of a phase is a compile-time constant (one code path per phase)
-template <int NS, bool EC, bool FROM_ZERO, int TRAIL, typename ET, int PO>
+// QK: the reference's 'dy' == 'dx' quirk (OF.py:698-699) as a compile-time constant (the select costs four instructions per point)
+template <int NS, bool EC, bool FROM_ZERO, int TRAIL, typename ET, int PO, int QK = 1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 2 : 1, FROM_ZERO ? 2 : 1))) void k_sweep0r(
     Fine0 pol, int ni, int nj, int TI, int /*po*/, int nx, int ny, int nz, const double* __restrict__ x_in,
     double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
     int fidx = pair;
     if (pol.pp) { alpha = pol.pp[pair].alpha; beta = pol.pp[pair].beta; fidx = pol.pp[pair].frame; }
     const double* img = pol.frames + (size_t)fidx * pol.frame_stride;
-    const int Nj = pol.Nj, quirks = pol.quirks;
+    const int Nj = pol.Nj;
+    constexpr int quirks = QK;
     const double inv_g = 1.0 / (-1 - 4 * beta);
 
     // lane <-> column pair (2 lane, 2 lane + 1); pair validity is all-or-nothing (qs and nj are even)
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 const bool rowok = EDGE ? (do_load && pL >= 0 && pL < ni) : true;
                 S0RRow& d = X[LO + 2 + r];
                 if (EDGE) d.u = d.w = d.g = double2{0.0, 0.0};
-                if (rowok && pair_ok) {
+                if (EDGE ? (rowok && pair_ok) : true) {   // (steady state = interior strip: every lane's pair exists)
                     const double* src = xin + (size_t)pL * nj + qg;
                     d.u = *reinterpret_cast<const double2*>(src);
                     d.w = *reinterpret_cast<const double2*>(src + npts);
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 if (EDGE) { li[r] = double2{0.0, 0.0}; lix[r] = double2{0.0, 0.0}; }
                 if (rowok) {
                     const double* frow = img + (size_t)pI * Nj;
-                    if (ipair_ok) li[r] = *reinterpret_cast<const double2*>(frow + iqg);
-                    if (xpair_ok) lix[r] = *reinterpret_cast<const double2*>(frow + xq);
+                    if (EDGE ? ipair_ok : true) li[r] = *reinterpret_cast<const double2*>(frow + iqg);
+                    if (EDGE ? xpair_ok : true) lix[r] = *reinterpret_cast<const double2*>(frow + xq);   // (steady state: every lane reads the same pair)
                 }
             }
         }
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             for (int f = 0; f < 3; ++f) {
                 crv[f] = 0;
                 const int c0 = cqs + lane;
-                if (knew >= 0 && knew < nci && c0 >= 0 && c0 < ncj) crv[f] = ec[(size_t)f * ncpts + (size_t)knew * ncj + c0];
+                if (EDGE ? (knew >= 0 && knew < nci && c0 >= 0 && c0 < ncj) : true) crv[f] = ec[(size_t)f * ncpts + (size_t)knew * ncj + c0];
             }
         }
     };
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         const int rr = e_next - st, p = p0 + rr;
         const bool rowok = EDGE ? (rr >= st_lo(st) && rr <= st_hi(st) && p >= 0 && p < ni) : true;
         if (EDGE) B[st][0] = B[st][1] = B[st][2] = double2{0.0, 0.0};
-        if (rowok && pair_ok) {
+        if (EDGE ? (rowok && pair_ok) : true) {
             const double* brow = bp + (size_t)p * nj + qg;
             B[st][0] = *reinterpret_cast<const double2*>(brow);
             B[st][1] = *reinterpret_cast<const double2*>(brow + npts);
@@ -204,8 +206,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
     };
 
     // ---- one colour stage: the two colours of window row jc (relative row rr), first the columns of true parity po
-    auto stage = [&](auto edge_tag, auto jc_tag, int rr, const double2 (&bs)[3]) {
+    auto stage = [&](auto edge_tag, auto border_tag, auto jc_tag, int rr, const double2 (&bs)[3]) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr bool BORDER = decltype(border_tag)::value;   // the strip touches the left / right side of the image
         constexpr int jc = decltype(jc_tag)::value;
         const int p = p0 + rr;
         const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
                 n.u[3] = lane_shr1(RC.u.y); n.w[3] = lane_shr1(RC.w.y); n.g[3] = lane_shr1(RC.g.y);
                 n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
-                if (border_strip && glE) {   // ghost column -1 mirrors column 1
+                if (BORDER && glE) {   // ghost column -1 mirrors column 1
                     gl = true;
                     n.u[0] = n.u[2]; n.w[0] = n.w[2]; n.u[3] = n.u[5]; n.w[3] = n.w[5]; n.g[3] = n.g[5]; n.u[6] = n.u[8]; n.w[6] = n.w[8];
                 }
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
                 n.u[5] = lane_shl1(RC.u.x); n.w[5] = lane_shl1(RC.w.x); n.g[5] = lane_shl1(RC.g.x);
                 n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
-                if (border_strip && grO) {   // ghost column n_j mirrors column n_j - 2
+                if (BORDER && grO) {   // ghost column n_j mirrors column n_j - 2
                     gr = true;
                     n.u[2] = n.u[0]; n.w[2] = n.w[0]; n.u[5] = n.u[3]; n.w[5] = n.w[3]; n.g[5] = n.g[3]; n.u[8] = n.u[6]; n.w[8] = n.w[6];
                 }
@@ -277,8 +280,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
     };
 
     // ---- trailing operator stage on window row jc (final, and so are its neighbours): v = A x_out + the dot products
-    auto trail_row = [&](auto edge_tag, auto jc_tag, int rr, auto slot_tag) {
+    auto trail_row = [&](auto edge_tag, auto border_tag, auto jc_tag, int rr, auto slot_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr bool BORDER = decltype(border_tag)::value;
         constexpr int jc = decltype(jc_tag)::value < 1 ? 1 : decltype(jc_tag)::value;   // (never instantiated below 1 when TRAIL is set)
         constexpr int slot = decltype(slot_tag)::value;
         const int p = p0 + rr;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         {   // the dot partner of the NEXT step's row
             const bool nrow = EDGE ? (rr + 2 >= 0 && rr + 2 < TI && p + 2 >= 0 && p + 2 < ni) : true;
             if (EDGE) tn[slot][0] = tn[slot][1] = tn[slot][2] = double2{0.0, 0.0};
-            if (tr.dotvec && nrow && st_ok) {
+            if (tr.dotvec && nrow && (EDGE ? st_ok : true)) {
                 const double* drow = tr.dotvec + off + (size_t)(p + 2) * nj + qg;
                 tn[slot][0] = *reinterpret_cast<const double2*>(drow);
                 tn[slot][1] = *reinterpret_cast<const double2*>(drow + npts);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
                 n.u[3] = lane_shr1(RC.u.y); n.w[3] = lane_shr1(RC.w.y); n.g[3] = lane_shr1(RC.g.y);
                 n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
-                if (border_strip && glE) {
+                if (BORDER && glE) {
                     gl = true;
                     n.u[0] = n.u[2]; n.w[0] = n.w[2]; n.u[3] = n.u[5]; n.w[3] = n.w[5]; n.g[3] = n.g[5]; n.u[6] = n.u[8]; n.w[6] = n.w[8];
                 }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
                 n.u[5] = lane_shl1(RC.u.x); n.w[5] = lane_shl1(RC.w.x); n.g[5] = lane_shl1(RC.g.x);
                 n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
-                if (border_strip && grO) {
+                if (BORDER && grO) {
                     gr = true;
                     n.u[2] = n.u[0]; n.w[2] = n.w[0]; n.u[5] = n.u[3]; n.w[5] = n.w[3]; n.g[5] = n.g[3]; n.u[8] = n.u[6]; n.w[8] = n.w[6];
                 }
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         }
     };
 
-    auto step = [&](auto edge_tag, const int e) {
+    auto step = [&](auto edge_tag, auto border_tag, const int e) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         // ---- (1) requests for rows e + 2, e + 3 (into the top of the window, first touched by the rotation below)
         request_rows(edge_tag, e);
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             constexpr int ST = decltype(st_tag)::value;
             const int rr = e - ST, p = p0 + rr;
             const bool rowok = EDGE ? (rr >= st_lo(ST) && rr <= st_hi(ST) && p >= 0 && p < ni) : true;
-            if (rowok) stage(edge_tag, std::integral_constant<int, LO - ST>{}, rr, B[ST]);
+            if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, B[ST]);
             request_b(edge_tag, st_tag, e + 2);
         };
         run_stage(std::integral_constant<int, 0>{});
@@ -393,8 +397,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         }
         // ---- (3) trailing stage on the rows that have just become final: e - 2 NS + 1 and e - 2 NS
         if constexpr (TRAIL != 0) {
-            trail_row(edge_tag, std::integral_constant<int, LO - 2 * NS + 1>{}, e - 2 * NS + 1, std::integral_constant<int, 1>{});
-            trail_row(edge_tag, std::integral_constant<int, LO - 2 * NS>{}, e - 2 * NS, std::integral_constant<int, 0>{});
+            trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS + 1>{}, e - 2 * NS + 1, std::integral_constant<int, 1>{});
+            trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS>{}, e - 2 * NS, std::integral_constant<int, 0>{});
         }
         // ---- (4) write-out of rows e - 2 NS, e - 2 NS + 1
 #pragma unroll
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                     char* dst = irow(r);
                     *reinterpret_cast<double*>(dst + lane * 8) = li[r].x;
                     *reinterpret_cast<double*>(dst + IHB + lane * 8) = li[r].y;
-                    if (lane == 0) {
+                    if (EDGE ? lane == 0 : true) {   // (steady state: all lanes hold the same pair and write it to the same place)
                         *reinterpret_cast<double*>(dst + 64 * 8) = lix[r].x;
                         *reinterpret_cast<double*>(dst + IHB + 64 * 8) = lix[r].y;
                     }
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             for (int r = 0; r < 2; ++r) {
                 const int pL = pL0 + r;
                 const bool rowok = EDGE ? (e + 3 <= TI + 2 * (NS + EXT) - 1 && pL >= 0 && pL < ni) : true;
-                if (rowok && pair_ok) {
+                if (EDGE ? (rowok && pair_ok) : true) {
                     const int cp = pL >> 1;
                     const bool ipi = (pL & 1) && (cp + 1 < nci);
                     const bool ipj = (qpair >> 1) + 1 < ncj;          // the odd column has a right coarse neighbour
@@ -498,8 +502,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
 
     for (int s = s_first; s <= s_last; ++s) {
         const int e = 2 * s;
-        if (e >= e_lo && e <= e_hi) step(std::false_type{}, e);
-        else step(std::true_type{}, e);
+        // (strips that touch a side of the image run the edge version throughout: the steady-state version then has no
+        // per-phase branch at all and is one basic block per step)
+        if (e >= e_lo && e <= e_hi && !border_strip) step(std::false_type{}, std::false_type{}, e);
+        else step(std::true_type{}, std::true_type{}, e);
     }
     if constexpr (TRAIL != 0) {   // per-block partial sums of the dot products
         const double a0 = wave_sum(ts0), a1 = wave_sum(ts1);

@@ -280,7 +280,7 @@ def variational_optical_flow(movie,
                                                     initial_remodelling, use_direct_solver, rtol, max_iterations,
                                                     reference_quirks, coarse_precision, vcycle_precision, multigrid_sweeps,
                                                     w_cycle_level, krylov_method, gmres_restart, warm_start_stride, preconditioner),
-                                                delta_x, delta_t)
+                                                delta_x, delta_t, direct_fallback=bool(use_direct_solver and preconditioner is None))
     if output != "numpy":
         raise ValueError("output must be 'numpy' or 'torch'")
     movie = _float64_copy(np.asarray(movie))                           # OF.py:769
@@ -340,7 +340,7 @@ def variational_optical_flow(movie,
 
 
 def _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_in_flight, verbose, return_stats,
-                                     reference_quirks, params, delta_x, delta_t):
+                                     reference_quirks, params, delta_x, delta_t, direct_fallback=False):
     """``output="torch"`` branch of ``variational_optical_flow``: torch only allocates the device arrays."""
     import torch
     dev = torch.device("cuda", int(device))
@@ -366,7 +366,8 @@ def _variational_optical_flow_device(movie, smoothing_sigma, device, max_pairs_i
         try:
             stats = solver.solve_dev(movie_to_analyse, T, params, out[0], out[1], out[2], out[3])
         except _native.VofError as exc:
-            if params.preconditioner != 1 or not _direct_unavailable(exc):
+            # same rule as the host path: only use_direct_solver=True (not an explicit preconditioner="direct") may fall back
+            if not (direct_fallback and _direct_unavailable(exc)):
                 raise
             params.preconditioner = 2
             stats = solver.solve_dev(movie_to_analyse, T, params, out[0], out[1], out[2], out[3])

@@ -495,6 +495,42 @@ def test_hard_regimes_are_rescued_by_the_direct_preconditioner(of, n, alpha, bet
     check_fields(res2, ref, 1e-6)
 
 
+@pytest.mark.parametrize("name,alpha,beta", [("T", 1e4, 1e2), ("W", 2e3, 1.0)])
+def test_real_data_regimes_at_258_with_default_arguments(of, name, alpha, beta):
+    """The reference's own real-data regimes (T: analyse_variational_optical_flow.py:201-233, 8-bit data with
+    speed_alpha 1e4; W: analyse_short_timeinterval_data.py:835, speed_alpha 2e3) at 258 x 258 with DEFAULT arguments only:
+    the multigrid path does not converge there, the automatic re-solve with the direct preconditioner (m = 768 unknowns per
+    image row: the in-house blocked inverse on the FP64 matrix cores, no rocSOLVER) must leave every pair converged by the
+    rule on the independent residual, and the answer is the exact solution of the reference system (oracle, SuperLU)."""
+    movie = np.round(orc.make_texture_stack(258, 2, seed=5) * 255.0)
+    res = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, return_stats=True)
+    st = res["stats"]
+    assert st["converged"].all() and st["relative_residual"].max() <= 1e-6, st
+    assert res["converged"] is True
+    ref = orc.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta)
+    check_fields(res, ref, 1e-4)     # what the reference's own stopping rule (rtol 1e-6) implies in these regimes
+    # the reference's switch: exact to the tight tolerance in a few Krylov steps
+    res2 = of.variational_optical_flow(movie, speed_alpha=alpha, remodelling_alpha=beta, use_direct_solver=True, return_stats=True)
+    assert res2["stats"]["converged"].all() and res2["stats"]["iterations"].max() <= 4, res2["stats"]
+    check_fields(res2, ref, 1e-6)
+
+
+def test_real_data_regime_at_514_by_the_cpu_residual(of):
+    """Regime T at 514 x 514 (1536 unknowns per image row, 9.7 GB of inverse Schur blocks for the pair), default arguments:
+    converged by the library's rule, and the same residual evaluated on the CPU from the returned fields (the oracle's
+    direct solve would take minutes at this size)."""
+    movie = np.round(orc.make_texture_stack(514, 2, seed=5) * 255.0)
+    res = of.variational_optical_flow(movie, speed_alpha=1e4, remodelling_alpha=1e2, return_stats=True)
+    st = res["stats"]
+    assert st["converged"].all(), st
+    xi = np.stack([res[f][0] for f in ("v_x", "v_y", "remodelling")])[:, 1:-1, 1:-1]
+    b = orc.rhs_interior(movie[0], movie[1])
+    r = b - orc.apply_operator_interior(movie[0], xi, 1e4, 1e2)
+    rel = np.linalg.norm(r) / np.linalg.norm(b)
+    assert rel <= 1e-6 * (1 + 1e-6), rel
+    assert rel == pytest.approx(st["relative_residual"][0], rel=1e-4)
+
+
 def test_parameter_sweep_of_the_reference_script_on_8bit_data(of):
     """AVOF.py:608-615: vary_regularisation over logspace(-1, 4) x logspace(-1, 4) on a down-sampled 8-bit stack with
     smoothing_sigma=1 and use_direct_solver=True - almost all of that grid lies in the regimes the multigrid cycle does not
