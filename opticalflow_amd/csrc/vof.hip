@@ -16,6 +16,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1984,8 +1986,14 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
         size_t addr = ((size_t)(uintptr_t)mbase + want + 4095) & ~(size_t)4095;
         split = std::min(movie_bytes, addr - (size_t)(uintptr_t)mbase);
     }
+    const bool htrace = getenv("VOF_TRACE_HOST") != nullptr;
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto hmark = [&](const char* what) {
+        if (htrace) fprintf(stderr, "[vof host] %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count(), what);
+    };
     const bool pinned_a = hipHostRegister((void*)mbase, split, hipHostRegisterDefault) == hipSuccess;
     if (!pinned_a) (void)hipGetLastError();
+    hmark("first movie part pinned");
     bool pinned_b = false;
     // Freshly allocated output arrays (np.empty) are not resident yet: first-touch page faults would serialise with
     // the device-to-host copies (0.6 s for 8 GB).  Helper threads prepare them while the GPU solves the first batch
@@ -1993,7 +2001,6 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
     // that the copies run at the pinned rate and asynchronously; arrays below 1 MB are only touched.
     double* outs[4] = {v_x, v_y, remodelling, speed};
     const size_t out_bytes = (size_t)P * fs * sizeof(double);
-    bool out_pinned[4] = {false, false, false, false};
     std::vector<std::thread> helpers;
     std::thread movie_helper;
     if (split < movie_bytes)
@@ -2001,15 +2008,73 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
             if (hipSetDevice(dev) == hipSuccess &&
                 hipHostRegister((void*)(mbase + split), movie_bytes - split, hipHostRegisterDefault) == hipSuccess) pinned_b = true;
         });
+    // Output regions: array i is cut at the batch boundaries (moved up to the next page so that no two registrations share
+    // a page); region (bi, i) is what batch bi's copy of array i writes, apart from the < 4 KB before its first page, which
+    // belongs to region bi - 1.  A pool of helper threads prepares the regions IN BATCH ORDER while the GPU solves: a region
+    // is pinned in place (which faults its pages in; 8.6 GB of fresh np.empty pages cost ~0.4 s of first-touch faults -
+    // round 2 pinned each array whole and the first batch's copies waited for all of it), arrays below 1 MB are only
+    // touched.  The copies of batch bi wait for batch bi's regions alone.
     const bool pin_outputs = out_bytes >= ((size_t)1 << 20);   // pageable device-to-host copies can drop to ~2 GB/s
-    for (int i = 0; i < 4; ++i)
-        if (outs[i])
-            helpers.emplace_back([ptr = (volatile char*)outs[i], out_bytes, pin_outputs, dev = c->device, flag = &out_pinned[i]]() {
-                if (pin_outputs && hipSetDevice(dev) == hipSuccess &&
-                    hipHostRegister((void*)ptr, out_bytes, hipHostRegisterDefault) == hipSuccess) { *flag = true; return; }
-                for (size_t o = 0; o < out_bytes; o += 4096) ptr[o] = 0;
-                if (out_bytes) ptr[out_bytes - 1] = 0;
-            });
+    std::vector<size_t> bound((size_t)nb + 1);                 // byte offsets of the region boundaries inside an output array
+    struct Region { char* ptr; size_t bytes; bool pinned; };
+    std::vector<Region> regions((size_t)nb * 4, Region{nullptr, 0, false});
+    std::vector<std::atomic<int>> batch_ready((size_t)nb);
+    for (auto& a : batch_ready) a.store(0);
+    int n_outs = 0;
+    for (int i = 0; i < 4; ++i) if (outs[i]) ++n_outs;
+    for (int i = 0; i < 4; ++i) {
+        if (!outs[i]) continue;
+        const uintptr_t base = (uintptr_t)outs[i];
+        for (int bi = 0; bi <= nb; ++bi) {
+            size_t o = bi == nb ? out_bytes : (size_t)batches[bi].k0 * fs * sizeof(double);
+            if (bi > 0 && bi < nb) o = std::min(out_bytes, (size_t)(((base + o + 4095) & ~(uintptr_t)4095) - base));
+            bound[(size_t)bi] = o;   // (the same for every array only if their bases share the page offset: kept per array below)
+            if (bi > 0) regions[(size_t)(bi - 1) * 4 + i].bytes = o;   // provisional: end offset
+        }
+        size_t prev = 0;
+        for (int bi = 0; bi < nb; ++bi) {
+            Region& r = regions[(size_t)bi * 4 + i];
+            const size_t end = r.bytes;
+            r.ptr = (char*)outs[i] + prev;
+            r.bytes = end - prev;
+            prev = end;
+        }
+    }
+    std::atomic<int> next_task{0};
+    const int n_tasks = nb * 4;
+    // The helpers only TOUCH the pages (plain stores: no runtime call, no lock shared with the launching thread - eight
+    // threads inside hipHostRegister slowed the solver's kernel launches threefold); registering resident pages afterwards
+    // takes ~2 ms per GB and is done by the calling thread just before the batch's copies.
+    auto helper_body = [&regions, &batch_ready, &next_task, n_tasks]() {
+        for (;;) {
+            const int t = next_task.fetch_add(1);
+            if (t >= n_tasks) return;
+            Region& r = regions[(size_t)t];
+            if (r.ptr && r.bytes) {
+                volatile char* q = (volatile char*)r.ptr;
+                for (size_t o = 0; o < r.bytes; o += 4096) q[o] = 0;
+                q[r.bytes - 1] = 0;
+            }
+            batch_ready[(size_t)(t / 4)].fetch_add(1);
+        }
+    };
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int n_helpers = (int)std::min<unsigned>(std::min<unsigned>(8u, hw), (unsigned)n_tasks);
+        for (int t = 0; t < n_helpers; ++t) helpers.emplace_back(helper_body);
+    }
+    int regions_pinned_upto = 0;
+    auto wait_batch_regions = [&](int bi) {   // every region of batch bi (and of the batches before it) is resident and pinned
+        for (int b = 0; b <= bi; ++b)
+            while (batch_ready[(size_t)b].load() < 4) std::this_thread::yield();
+        for (; regions_pinned_upto <= bi; ++regions_pinned_upto)
+            for (int i = 0; i < 4 && pin_outputs; ++i) {
+                Region& r = regions[(size_t)regions_pinned_upto * 4 + i];
+                if (!r.ptr || !r.bytes) continue;
+                if (hipHostRegister((void*)r.ptr, r.bytes, hipHostRegisterDefault) == hipSuccess) r.pinned = true;
+                else (void)hipGetLastError();
+            }
+    };
     auto join_helpers = [&]() { for (auto& t : helpers) if (t.joinable()) t.join(); };
     auto fail_msg = [&](const char* what, hipError_t e) { c->err = std::string(what) + ": " + hipGetErrorString(e); return -2; };
     int rc_all = 0;
@@ -2049,7 +2114,9 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
         }
         int rc = solve_range_dev(c, frames_buf[set], bt.np, so[0], so[1], so[2], so[3], stats ? stats + bt.k0 : nullptr);
         if (rc) { rc_all = rc; break; }
-        join_helpers();
+        hmark("batch solved");
+        wait_batch_regions(bi);
+        hmark("output regions of the batch ready");
         hipStream_t cs = multi ? c->copy_stream : c->stream;
         if (multi) {
             if ((e = hipEventRecord(c->ev_solved[set], c->stream)) != hipSuccess ||
@@ -2057,8 +2124,18 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
         }
         for (int i = 0; i < 4 && !rc_all; ++i)
             if (outs[i]) {
-                e = hipMemcpyAsync(outs[i] + (size_t)bt.k0 * fs, so[i], (size_t)bt.np * fs * sizeof(double), hipMemcpyDeviceToHost, cs);
-                if (e != hipSuccess) rc_all = fail_msg("D2H copy failed", e);
+                // the batch's bytes [o0, o1) of array i: the part before region bi's first page lies in region bi - 1
+                const size_t o0 = (size_t)bt.k0 * fs * sizeof(double), o1 = o0 + (size_t)bt.np * fs * sizeof(double);
+                const size_t r0 = (size_t)(regions[(size_t)bi * 4 + i].ptr - (char*)outs[i]);
+                const size_t cut = std::min(std::max(r0, o0), o1);
+                if (cut > o0) {
+                    e = hipMemcpyAsync((char*)outs[i] + o0, (const char*)so[i], cut - o0, hipMemcpyDeviceToHost, cs);
+                    if (e != hipSuccess) { rc_all = fail_msg("D2H copy failed", e); break; }
+                }
+                if (o1 > cut) {
+                    e = hipMemcpyAsync((char*)outs[i] + cut, (const char*)so[i] + (cut - o0), o1 - cut, hipMemcpyDeviceToHost, cs);
+                    if (e != hipSuccess) rc_all = fail_msg("D2H copy failed", e);
+                }
             }
         if (multi) {
             if (!rc_all && (e = hipEventRecord(c->ev_copied[set], cs)) != hipSuccess) rc_all = fail_msg("event record failed", e);
@@ -2066,12 +2143,15 @@ int vof_solve_stack_host(vof_ctx* c, const double* movie, int n_frames, const vo
     }
     join_helpers();
     if (movie_helper.joinable()) movie_helper.join();
+    hmark("all batches enqueued");
     if (multi && hipStreamSynchronize(c->copy_stream) != hipSuccess && !rc_all) { c->err = "copy stream synchronize failed"; rc_all = -2; }
     if (hipStreamSynchronize(c->stream) != hipSuccess && !rc_all) { c->err = "stream synchronize failed"; rc_all = -2; }
-    for (int i = 0; i < 4; ++i)
-        if (out_pinned[i]) (void)hipHostUnregister((void*)outs[i]);
+    hmark("copies done");
+    for (auto& r : regions)
+        if (r.pinned) (void)hipHostUnregister((void*)r.ptr);
     if (pinned_a) (void)hipHostUnregister((void*)mbase);
     if (pinned_b) (void)hipHostUnregister((void*)(mbase + split));
+    hmark("unpinned");
     return rc_all;
 }
 
