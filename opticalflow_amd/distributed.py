@@ -39,11 +39,17 @@ def _gather_stack(local, counts, group):
     return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0)
 
 
-def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=None, output="numpy", **kwargs):
+def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=None, output="numpy", n_frames=None,
+                                     gather_movie=None, **kwargs):
     """Solve a stack across all ranks of ``group`` and return the full result dict on every rank.
 
     ``movie`` is the full (T, N_i, N_j) stack (every rank passes the same array or device tensor; only its own frame
-    range is read).  Rank r solves the contiguous pair range ``shard_pair_range(T - 1, world, r)`` on its own GPU with
+    range is read) - or a FRAME PROVIDER ``movie(first_frame, count) -> (count, N_i, N_j)`` array / device tensor together
+    with ``n_frames=T``: each rank then asks for exactly the frames of its own pairs (generated or loaded on its GPU, as
+    bench.py does) and no rank ever holds the whole movie.  ``gather_movie`` (default: True for an
+    array, False for a provider): whether ``original_data`` / ``blurred_data`` are the whole movie on every rank
+    (all-gathered from the shards when it comes from a provider) or this rank's frames only, in which case
+    ``result["frame_range"] = (first, last + 1)`` says which.  Rank r solves the contiguous pair range ``shard_pair_range(T - 1, world, r)`` on its own GPU with
     the device-resident drop-in (``variational_optical_flow(..., output="torch")``), and the flow fields are re-assembled
     straight from the solver's device outputs with one ``all_gather_into_tensor`` per field (RCCL over xGMI; layout
     [rank][pair] = natural order).  ``output="numpy"`` (default, the reference's contract OF.py:1193-1197) copies the
@@ -67,10 +73,23 @@ def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=No
         device = torch.device("cpu")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    provider = movie if callable(movie) else None
+    if provider is not None:
+        if n_frames is None:
+            raise ValueError("a frame provider needs n_frames (the length of the whole stack)")
+        T = int(n_frames)
+        start, stop = shard_pair_range(T - 1, world, rank)
+        # (an empty shard still asks for one frame: the frame shape of the re-assembled stack)
+        movie = provider(start, stop - start + 1) if stop > start else provider(min(start, T - 1), 1)
+        frame0 = start if stop > start else min(start, T - 1)
+    if gather_movie is None:
+        gather_movie = provider is None
     is_tensor = hasattr(movie, "data_ptr")
     if not is_tensor:
         movie = np.asarray(movie)
-    T = movie.shape[0]
+    if provider is None:
+        T = movie.shape[0]
+        frame0 = 0
     P = T - 1
     frame_shape = tuple(movie.shape[1:])
     counts = [shard_pair_range(P, world, r)[1] - shard_pair_range(P, world, r)[0] for r in range(world)]
@@ -83,7 +102,7 @@ def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=No
         return torch.as_tensor(a).to(device=device, dtype=torch.float64)
 
     if stop > start:
-        sub = solve_fn(movie[start: stop + 1], **kwargs)      # one overlap frame per shard
+        sub = solve_fn(movie[start - frame0: stop + 1 - frame0], **kwargs)      # one overlap frame per shard
         local = {k: on_device(sub[k]) for k in fields}
         scal[:] = (sub["L1_functional"], sub["remodelling_functional"], sub["speed_functional"],
                    float(bool(sub["converged"])))
@@ -99,14 +118,30 @@ def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=No
     flags = torch.zeros(world, dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(flags, torch.as_tensor(scal[3:4].copy(), device=device), group=group)
     last_rank = max(r for r in range(world) if counts[r] > 0)
-    movie64 = on_device(movie) if output == "torch" else (movie.cpu().numpy() if is_tensor else movie).astype(np.float64)
+
+    def whole_stack(frames):
+        """Frames of this rank's pairs (+ the final frame on the last non-empty rank) -> the whole stack on every rank."""
+        body = _gather_stack(frames[: counts[rank]], counts, group)
+        lastf = torch.zeros((world,) + frame_shape, dtype=torch.float64, device=device)
+        tail = frames[counts[rank]: counts[rank] + 1] if frames.shape[0] > counts[rank] else torch.zeros((1,) + frame_shape, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(lastf, tail.contiguous(), group=group)
+        return torch.cat([body, lastf[last_rank: last_rank + 1]], dim=0)
+
+    own = slice(start - frame0, stop + 1 - frame0) if stop > start else slice(0, 0)
+    if provider is None and gather_movie:
+        # (the caller holds the whole movie anyway; round 2 made this float64 copy of ALL of it on every rank even when
+        # only the shard was wanted - 8 x 8 GiB of host memory at BASELINE config 4)
+        movie64 = on_device(movie) if output == "torch" else (movie.cpu().numpy() if is_tensor else movie).astype(np.float64)
+    elif gather_movie:
+        full = whole_stack(on_device(movie[own]) if stop > start else torch.zeros((0,) + frame_shape, dtype=torch.float64, device=device))
+        movie64 = full if output == "torch" else full.cpu().numpy()
+    else:
+        mine = movie[own]
+        movie64 = on_device(mine) if output == "torch" else (mine.cpu().numpy() if is_tensor else np.asarray(mine)).astype(np.float64)
     if blur:
         # the blurred stack the solves ran on (OF.py:1199): every rank contributes the frames of its pairs, the last
         # non-empty rank also the final frame (the blur is per frame, so the overlap frames agree)
-        body = _gather_stack(blurred[: counts[rank]], counts, group)
-        lastf = torch.zeros((world,) + frame_shape, dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(lastf, blurred[counts[rank]: counts[rank] + 1].contiguous(), group=group)
-        blurred_full = torch.cat([body, lastf[last_rank: last_rank + 1]], dim=0)
+        blurred_full = whole_stack(blurred) if gather_movie else (blurred[: counts[rank] + 1] if stop > start else blurred[:0])
     result = dict(out)
     result["speed"] = torch.sqrt(out["v_x"] ** 2 + out["v_y"] ** 2)
     if output == "numpy":
@@ -116,6 +151,8 @@ def variational_optical_flow_sharded(movie, solve_fn=None, group=None, device=No
         result["blurred_data"] = blurred_full if output == "torch" else blurred_full.cpu().numpy()
     else:
         result["blurred_data"] = movie64                      # same object, as in the reference (OF.py:773)
+    if not gather_movie:
+        result["frame_range"] = (start, stop + 1) if stop > start else (start, start)
     result["delta_x"] = kwargs.get("delta_x", 1.0)
     result["delta_t"] = kwargs.get("delta_t", 1.0)
     result["converged"] = bool(flags[last_rank].item())

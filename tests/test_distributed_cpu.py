@@ -95,6 +95,68 @@ def test_two_rank_gloo_sharded_solve_matches_single_process(n_frames, sigma, out
         assert conv is True
 
 
+def _provider_worker(rank, world, port, n_frames, q, gather_movie, sigma):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import vof_oracle as orc
+        from opticalflow_amd.distributed import variational_optical_flow_sharded
+        asked = []
+
+        def provider(first, count):                      # this rank's frames only (the generator takes a first_frame offset)
+            asked.append((first, count))
+            return orc.make_texture_stack(24, count, seed=5, first_frame=first)
+
+        def solve_fn(sub, **kw):
+            return orc.variational_optical_flow(sub, **kw)
+
+        kw = dict(speed_alpha=1.0, remodelling_alpha=50.0, delta_x=0.5, delta_t=1.0)
+        if sigma is not None:
+            kw["smoothing_sigma"] = sigma
+        res = variational_optical_flow_sharded(provider, solve_fn=solve_fn, n_frames=n_frames, gather_movie=gather_movie, **kw)
+        q.put((rank, asked, res["v_x"], res["original_data"], res["blurred_data"], res.get("frame_range"), res["L1_functional"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,gather_movie,sigma", [(6, False, None), (5, True, None), (2, False, None), (5, True, 1.5), (6, False, 1.5)])
+def test_two_rank_gloo_sharded_solve_from_a_frame_provider(n_frames, gather_movie, sigma):
+    """The sharded entry point with a per-rank frame provider: every rank asks for exactly the frames of its own pairs (+ the
+    overlap frame), nobody holds the whole movie unless gather_movie asks for it, results equal the single-process solve."""
+    from oracle import vof_oracle as orc
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_provider_worker, args=(r, world, port, n_frames, q, gather_movie, sigma)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    movie = orc.make_texture_stack(24, n_frames, seed=5)
+    ref = orc.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=50.0, delta_x=0.5, delta_t=1.0,
+                                       **({} if sigma is None else {"smoothing_sigma": sigma}))
+    P = n_frames - 1
+    for rank, asked, vx, orig, blurred, frange, L1 in got:
+        a, b = shard_pair_range(P, world, rank)
+        assert asked == ([(a, b - a + 1)] if b > a else [(min(a, n_frames - 1), 1)])
+        np.testing.assert_allclose(vx, ref["v_x"], rtol=1e-9, atol=1e-12)
+        assert L1 == pytest.approx(ref["L1_functional"], rel=1e-9)
+        if gather_movie:
+            assert frange is None
+            np.testing.assert_allclose(orig, movie, rtol=0, atol=1e-15)
+            np.testing.assert_allclose(blurred, ref["blurred_data"], rtol=0, atol=1e-15)
+        else:
+            assert frange == ((a, b + 1) if b > a else (a, a))
+            np.testing.assert_allclose(orig, movie[a: b + 1] if b > a else movie[:0], rtol=0, atol=1e-15)
+            np.testing.assert_allclose(blurred, ref["blurred_data"][a: b + 1] if b > a else movie[:0], rtol=0, atol=1e-15)
+
+
 def _gather_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
