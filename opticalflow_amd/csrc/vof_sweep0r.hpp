@@ -65,7 +65,9 @@ template <int NS, bool EC, bool FROM_ZERO, int TRAIL, typename ET, int PO, int Q
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 2 : 1, FROM_ZERO ? 2 : 1))) void k_sweep0r(
     Fine0 pol, int ni, int nj, int TI, int /*po*/, int nx, int ny, int nz, const double* __restrict__ x_in,
     double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
-    const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr) {
+    const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr, int skip_first = 0, int skip_count = 0) {
+    // (skip_first, skip_count: the strips [skip_first, skip_first + skip_count) belong to another launch - k_sweep0p takes the
+    // interior strips in its mode -; nx counts the strips of THIS launch)
     typedef S0R<NS, TRAIL> G;
     constexpr int W = S0_W, LO = G::LO, NRW = G::NRW, NRI = G::NRI, IRB = G::IRB, IHB = G::IPW * 8, EXT = G::EXT;
     constexpr int NST = 2 * NS, po = PO;                                  // stages per step: E_0, O_0, E_1, O_1, ...: stage st works on row e - st
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
     const unsigned nblocks = (unsigned)nx * ny * nz;
     unsigned lb = blockIdx.x;
     if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
-    const int bx = lb % nx, by = (lb / nx) % ny;
+    const int bxl = lb % nx, by = (lb / nx) % ny;
+    const int bx = bxl < skip_first ? bxl : bxl + skip_count;
     const int pair = lb / (nx * ny);
     if (active && !active[pair]) return;
     const int lane = threadIdx.x;
@@ -448,8 +451,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 const bool rowok = EDGE ? (e + 3 <= TI + 2 * (NS + EXT) - 1 && pL >= 0 && pL < ni) : true;
                 if (EDGE ? (rowok && pair_ok) : true) {
                     const int cp = pL >> 1;
-                    const bool ipi = (pL & 1) && (cp + 1 < nci);
-                    const bool ipj = (qpair >> 1) + 1 < ncj;          // the odd column has a right coarse neighbour
+                    // (steady state: the row parity is that of PO + r - TI and e are even -, the coarse row above exists and
+                    // every lane's odd column has its right coarse neighbour: no branch left)
+                    const bool ipi = EDGE ? ((pL & 1) && (cp + 1 < nci)) : (((PO + r) & 1) != 0);
+                    const bool ipj = EDGE ? ((qpair >> 1) + 1 < ncj) : true;   // the odd column has a right coarse neighbour
                     // coarse row cp: CR[cp - (pL0 >> 1)] (0 or 1); coarse row cp + 1: CR[1] or the row that has just arrived
                     const int i0 = cp - (pL0 >> 1);
                     S0RRow& d = X[LO + 2 + r];

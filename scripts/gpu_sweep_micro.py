@@ -11,7 +11,7 @@ NS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = int(os.environ.get("VOF_N", "1024"))
 s = _native.Solver(n, n, P)
 movie = texture_stack_torch(n, P + 1, 1, torch.device("cuda", 0), solver=s)
-prm = _native.default_params(remodelling_alpha=1e4)
+prm = _native.default_params(remodelling_alpha=1e4, vcycle_precision=int(os.environ.get("VOF_VP", "3")))
 s.bench_sweeps(movie, P, prm, NS)
 s.profile_enable(True)
 for rep in range(3):
