@@ -4,7 +4,7 @@
 // instructions per point update at 4.1-5 cycles each, 58-61 % of all SIMD cycles busy with them, clocks at 1.7-1.8 GHz), not
 // by HBM.  The smoother is part of the PRECONDITIONER: the Krylov iteration, its operator products, the residuals and the
 // stopping rule stay float64, and the cycle vectors below level 0 are float32 already (vcycle_precision 3).  Float32
-// arithmetic in the level-0 sweeps leaves every iteration count of the well-conditioned regimes unchanged (oracle
+// arithmetic in the level-0 sweeps leaves every iteration count of the well-conditioned regimes unchanged (CPU prototype
 // experiment, DESIGN.md section 3.1: N, 8-bit alpha 1e5, alpha = beta = 1, alpha 0.5, 8-bit alpha = beta = 1e6: the same
 // counts to rtol 1e-6 and 1e-10); the grad-div dominated regime T needs float64 there, which is what the solver switches
 // to after AUTO_F64_AFTER iterations anyway (together with the float64 cycle vectors).
