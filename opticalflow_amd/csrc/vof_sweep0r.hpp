@@ -293,8 +293,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         {   // the dot partner of the NEXT step's row
             const bool nrow = EDGE ? (rr + 2 >= 0 && rr + 2 < TI && p + 2 >= 0 && p + 2 < ni) : true;
             if (EDGE) tn[slot][0] = tn[slot][1] = tn[slot][2] = double2{0.0, 0.0};
-            if (tr.dotvec && nrow && (EDGE ? st_ok : true)) {
-                const double* drow = tr.dotvec + off + (size_t)(p + 2) * nj + qg;
+            // (no dot partner given: the loads read v itself - valid memory, values unused - so that the steady state has no branch)
+            const double* dv = tr.dotvec ? tr.dotvec : tr.v;
+            if (EDGE ? (tr.dotvec && nrow && st_ok) : true) {
+                const double* drow = dv + off + (size_t)(p + 2) * nj + qg;
                 tn[slot][0] = *reinterpret_cast<const double2*>(drow);
                 tn[slot][1] = *reinterpret_cast<const double2*>(drow + npts);
                 tn[slot][2] = *reinterpret_cast<const double2*>(drow + 2 * npts);
@@ -365,19 +367,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             if (par == 0) { y[0].x = y0; y[1].x = y1; y[2].x = y2; }
             else { y[0].y = y0; y[1].y = y1; y[2].y = y2; }
         }
+        // (only the three stores sit under the lane predicate: a short predicated region gets no skip branch, so the steady-state
+        // step stays one basic block; the sums of the lanes outside the owned columns are masked with a select)
         if (st_ok) {
             double* vrow = tr.v + off + (size_t)p * nj + qg;
             *reinterpret_cast<double2*>(vrow) = y[0];
             *reinterpret_cast<double2*>(vrow + npts) = y[1];
             *reinterpret_cast<double2*>(vrow + 2 * npts) = y[2];
-            const double vv = (y[0].x * y[0].x + y[1].x * y[1].x + y[2].x * y[2].x) + (y[0].y * y[0].y + y[1].y * y[1].y + y[2].y * y[2].y);
-            if (tr.dotvec) {
-                ts0 += (y[0].x * t0.x + y[1].x * t1.x + y[2].x * t2.x) + (y[0].y * t0.y + y[1].y * t1.y + y[2].y * t2.y);
-                ts1 += vv;
-            } else {
-                ts0 += vv;
-            }
         }
+        const double vv = (y[0].x * y[0].x + y[1].x * y[1].x + y[2].x * y[2].x) + (y[0].y * y[0].y + y[1].y * y[1].y + y[2].y * y[2].y);
+        const double vt = (y[0].x * t0.x + y[1].x * t1.x + y[2].x * t2.x) + (y[0].y * t0.y + y[1].y * t1.y + y[2].y * t2.y);
+        ts0 += st_ok ? (tr.dotvec ? vt : vv) : 0.0;
+        ts1 += st_ok ? vv : 0.0;
     };
 
     auto step = [&](auto edge_tag, auto border_tag, const int e) {
