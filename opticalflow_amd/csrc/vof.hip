@@ -1190,10 +1190,10 @@ struct RocSolverApi {
 RocSolverApi g_roc;
 
 // Dense inverse of the Schur blocks, all in-house: the one-workgroup Gauss-Jordan kernel with partial pivoting up to
-// DIRECT_OWN_MAX unknowns per image row (the down-sampled images the reference sweeps at), the blocked Gauss-Jordan on the
-// FP64 matrix cores beyond (vof_direct.hpp).  VOF_DIRECT_LU=own|blocked|rocsolver forces one (rocSOLVER getrf + getri,
+// DIRECT_OWN_MAX unknowns per image row (images up to 66 pixels wide), the blocked Gauss-Jordan on the FP64 matrix cores
+// beyond (vof_direct.hpp).  VOF_DIRECT_LU=own|blocked|rocsolver forces one (rocSOLVER getrf + getri,
 // round 2's choice for wide images, is loaded with dlopen only when asked for: an A/B reference, not a product path).
-constexpr int DIRECT_OWN_MAX = 640;
+constexpr int DIRECT_OWN_MAX = 192;   // (round 2: 640; the blocked inverse is 6.6 x faster on the reference's 400-combination sweep at 128 x 128: 29.6 -> 4.5 s)
 bool direct_uses_rocsolver(const vof_ctx*) {
     const char* e = getenv("VOF_DIRECT_LU");
     return e && e[0] == 'r';
@@ -1341,6 +1341,15 @@ int direct_apply_t(vof_ctx* c, VT* z, const VT* r, int np) {
 int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double* vy, double* gm, double* speed,
                 vof_pair_stats* stats) {
     const vof_params& P = c->prm;
+    // preconditioner 2 ("auto"): when the direct re-solve is available, the multigrid attempt is not run to the reference's
+    // 1000 iterations (OF.py:1120) - where the cycle works it needs 3 .. 100 Krylov steps, and a pair that
+    // has not converged after MG_ATTEMPT_CAP of them is handed to the direct preconditioner, which settles it in one or two
+    struct MaxItGuard { vof_params& p; int saved; ~MaxItGuard() { p.max_iterations = saved; } } max_it_guard{c->prm, c->prm.max_iterations};
+    constexpr int MG_ATTEMPT_CAP = 150;
+    // (images up to ~530 pixels wide, where the direct re-solve takes seconds: 3.3 s per pair at 514^2)
+    if (P.preconditioner == 2 && !c->direct_on && c->L.size() > 1 && P.max_iterations > MG_ATTEMPT_CAP && 3 * c->L[0].nj <= 1600 &&
+        direct_ok_for_fallback(c))
+        c->prm.max_iterations = MG_ATTEMPT_CAP;
     if (stats) HIPCHK(hipEventRecord(c->ev_batch[0], c->stream));
     // storage type of the cycle vectors for this batch (an earlier batch may have switched to float64: "auto"
     // precision after 8 iterations, GMRES fallback)

@@ -57,9 +57,9 @@ def main():
         # Level-0-only kernels: the band height adapts to the number of active pairs, so one solve launches the same
         # symbol with several grid sizes -> per-launch mean over all of them (what bench.py's per-launch figure is).
         # Stored-level kernels share a symbol across levels: label the grid with the largest total traffic (level 1).
-        # bench.py's classes: gs0 = every level-0 smoother pass (k_sweep0m / k_sweep0 / k_sweep<SweepFine> instantiations),
+        # bench.py's classes: gs0 = every level-0 smoother pass (k_sweep0r / k_sweep0m / k_sweep0 / k_sweep<SweepFine> instantiations),
         # apply0 = the level-0 operator kernels.  Their per-launch figure is the mean over ALL launches of the class.
-        merged = {"gs0": ("k_sweep0m<", "k_sweep0<", "k_sweep<vof::SweepFine"), "apply0": ("k_stream_apply0<", "k_stream_resrestrict0<")}
+        merged = {"gs0": ("k_sweep0r<", "k_sweep0m<", "k_sweep0<", "k_sweep<vof::SweepFine"), "apply0": ("k_stream_apply0<", "k_stream_resrestrict0<")}
         for nm, pats in merged.items():
             lst = [(sym, t) for sym, l2 in by_sym.items() if any(pt in sym for pt in pats) for t in l2]
             if not lst:
