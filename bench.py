@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--pairs-in-flight", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-6)
     ap.add_argument("--coarse-precision", default="float8", choices=["float64", "float32", "bfloat16", "float8"])
-    ap.add_argument("--vcycle-precision", default="coarse_float32", choices=["float64", "float32", "auto", "coarse_float32", "smoother_float32"])
+    ap.add_argument("--vcycle-precision", default="coarse_float32", choices=["float64", "float32", "auto", "coarse_float32"])
     ap.add_argument("--nu-pre", type=int, default=2)
     ap.add_argument("--nu-post", type=int, default=2)
     ap.add_argument("--nu-pre-coarse", type=int, default=1)
@@ -201,7 +201,7 @@ def main():
     sizes = chunk_plan(P, args.gather_chunks) if gather else [P]
     n_chunks = len(sizes)
     cp_arg = {"float64": 0, "float32": 1, "bfloat16": 2, "float8": 3}[args.coarse_precision]
-    vp_arg = {"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3, "smoother_float32": 4}[args.vcycle_precision]
+    vp_arg = {"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3}[args.vcycle_precision]
     # the variant runs below widen the stencil storage of the same context up to float64 (the context re-allocates it)
     per_pair = _native.query_workspace(n, n, 1, cp_arg if (args.no_variants or world > 1 or use_dist) else 0, vp_arg)
     free, total = _native.device_memory(local_rank)

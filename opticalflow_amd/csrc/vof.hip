@@ -8,13 +8,7 @@
 // advance together; per-pair scalars stay on the device.
 #include "vof_device.hpp"
 #include "vof_sweep0r.hpp"
-#ifndef VOF_EXP_SWEEP0P
-#define VOF_EXP_SWEEP0P 0   // 1: build the packed-float32 level-0 pass k_sweep0p and accept vcycle_precision 4 (experiment: measured
-                            // slower than k_sweep0r on the plain pass)
-#endif
-#if VOF_EXP_SWEEP0P
 #include "vof_sweep0p.hpp"
-#endif
 #include "vof_direct.hpp"
 #include "../../include/vof.h"
 
@@ -159,8 +153,8 @@ struct vof_ctx {
     bool sweep0m = true;        // level 0, float64 vectors, even n_j: k_sweep0m (VOF_SWEEP0M=0: k_sweep0)
     bool sweep0m_pairs = true;  // ... two sweeps per pass (VOF_SWEEP0M=1: one sweep per pass)
     bool sweep0r = true;        // ... the register-resident pass k_sweep0r (VOF_SWEEP0R=0: the LDS-ring pass k_sweep0m)
-    bool sweep0p = true;        // ... in packed float32 on the interior strips while smooth32 is on (VOF_SWEEP0P=0: never)
-    bool smooth32 = false;      // vcycle_precision 4, first iterations of a batch: float32 arithmetic in the level-0 smoother
+    bool sweep0p = true;        // level 0, float32 cycle vectors (vcycle_precision 1 / 2): the packed-float32 register-resident pass
+                                // k_sweep0p, two sweeps per pass (VOF_SWEEP0P=0: the LDS-ring kernel k_sweep0 with float64 arithmetic)
     bool tail_enabled = true;   // fused LDS-resident coarse-tail kernel (VOF_COARSE_TAIL=0: one launch per operation)
     int tail_first = -1;        // first level of the tail (-1: no tail for this grid)
     size_t tail_lds = 0;        // dynamic LDS bytes of k_tail_cycle
@@ -584,6 +578,12 @@ inline bool sweep0m_usable(const vof_ctx* c) {
     return c->sweep0m && c->sweep0 && c->fused && !c->geo_b_fine && !c->vfloat && (c->L[0].nj % 2 == 0) && c->L[0].C == nullptr;
 }
 
+// k_sweep0p (float32 cycle vectors: packed float32 arithmetic, two strips per wave, up to two sweeps per pass)
+inline bool sweep0p_usable(const vof_ctx* c) {
+    return c->sweep0p && c->sweep0r && c->sweep0 && c->fused && !c->geo_b_fine && c->vfloat && (c->L[0].nj % 2 == 0) && c->L[0].C == nullptr &&
+           c->prm.reference_quirks && c->pq_smooth;
+}
+
 // k_sweep_st: stored levels with packed bfloat16 stencils and the 128-column strip geometry
 inline bool sweep_st_usable(const vof_ctx* c, int l) {
     return l > 0 && c->L[l].C != nullptr && c->sweep_st && c->geo_b_stored && c->cfmt >= 2;
@@ -605,13 +605,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
         if (l == 0 && lv.C == nullptr && sweep0m_usable(c)) {
             // k_sweep0m: merged colours, 16-byte accesses, `nsweeps` (1 or 2) sweeps per pass; strips are not shifted by po
             const int NSW = nsweeps >= 2 ? 2 : 1;
-            // packed float32 arithmetic on the interior strips (k_sweep0p) while the batch is in its float32-smoother phase; the
-            // Krylov product then runs as its own float64 kernel (no trailing stage)
-            const int p_out = S0_W - 8 * NSW;
-            const int p_interior = std::max(0, (lv.nj - (S0_W - 4 * NSW)) / p_out);          // strips 1 .. p_interior lie inside the image
-            const bool packed = VOF_EXP_SWEEP0P && c->smooth32 && c->sweep0p && c->sweep0r && c->prm.reference_quirks && c->pq_smooth &&
-                                p_interior >= 2 && (!ecoarse || ec32);
-            const bool trail = with_trail && x_in != nullptr && !packed;
+            const bool trail = with_trail && x_in != nullptr;
             const int out = S0_W - 8 * NSW - (trail ? 4 : 0);
             const int nx = (lv.nj + out - 1) / out;
             const int TI = pick_band_height(rows, nx, c->cur_units);
@@ -657,27 +651,6 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0r<NS_, false, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
-#if VOF_EXP_SWEEP0P
-            if (packed) {
-                const int npairs_s = p_interior / 2;                      // strip pairs (1, 2), (3, 4), ...
-                const int nx_rest = nx - 2 * npairs_s;                    // the side strips (and an odd interior one): k_sweep0r below
-                const dim3 gp((unsigned)npairs_s * ny * np, 1, 1), gr((unsigned)nx_rest * ny * np, 1, 1);
-                const size_t ldsr = S0R<2, 0>::LDS_BYTES;
-#define VOF_LAUNCH_S0P(NS_, PO_)                                                                                                    \
-                do {                                                                                                                \
-                    if (ecoarse) { k_sweep0p<NS_, true, false, float, PO_><<<gp, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 1, npairs_s, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj); \
-                                   k_sweep0r<NS_, true, false, 0, float, PO_><<<gr, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx_rest, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr, 1, 2 * npairs_s); } \
-                    else if (!x_in) { k_sweep0p<NS_, false, true, float, PO_><<<gp, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 1, npairs_s, ny, np, x_in, x_out, b, active, nullptr, 0, 0); \
-                                      k_sweep0r<NS_, false, true, 0, double, PO_><<<gr, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx_rest, ny, np, x_in, x_out, b, active, nullptr, 0, 0, tr, 1, 2 * npairs_s); } \
-                    else { k_sweep0p<NS_, false, false, float, PO_><<<gp, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 1, npairs_s, ny, np, x_in, x_out, b, active, nullptr, 0, 0); \
-                           k_sweep0r<NS_, false, false, 0, double, PO_><<<gr, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx_rest, ny, np, x_in, x_out, b, active, nullptr, 0, 0, tr, 1, 2 * npairs_s); } \
-                } while (0)
-                if (NSW == 2) { if (po) VOF_LAUNCH_S0P(2, 1); else VOF_LAUNCH_S0P(2, 0); }
-                else { if (po) VOF_LAUNCH_S0P(1, 1); else VOF_LAUNCH_S0P(1, 0); }
-#undef VOF_LAUNCH_S0P
-            }
-            else
-#endif
             if (c->sweep0r && f0.quirks) {   // (the register-resident pass is compiled with the reference's derivative quirk built in)
                 if (NSW == 2) { if (po) VOF_LAUNCH_S0R(2, 1); else VOF_LAUNCH_S0R(2, 0); }
                 else { if (po) VOF_LAUNCH_S0R(1, 1); else VOF_LAUNCH_S0R(1, 0); }
@@ -685,6 +658,33 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             else if (NSW == 2) VOF_LAUNCH_S0M(2); else VOF_LAUNCH_S0M(1);
 #undef VOF_LAUNCH_S0R
 #undef VOF_LAUNCH_S0M
+            return;
+        }
+    }
+    if constexpr (std::is_same<VT, float>::value) {
+        if (l == 0 && lv.C == nullptr && sweep0p_usable(c)) {
+            const int NSW = nsweeps >= 2 ? 2 : 1;
+            const int out = S0_W - 8 * NSW;
+            const int nx = (lv.nj + out - 1) / out, nxp = (nx + 1) / 2;
+            const int TI = pick_band_height(rows, nxp, c->cur_units);
+            const int ny = (rows + TI - 1) / TI;
+            dim3 g((unsigned)nxp * ny * np, 1, 1);
+            int nci = 0, ncj = 0;
+            double ebytes = 0.0;
+            if (ecoarse) { nci = c->L[1].ni; ncj = c->L[1].nj; ebytes = 12.0 * c->L[1].npts; }
+            const double moved = (8.0 + (x_in ? 9.0 : 6.0) * 4.0) * lv.npts + ebytes;   // I + b(3) + x(3) in, x(3) out, float32 vectors
+            Prof p(c, VOF_K_GS0, 0, moved + (NSW - 1) * 44.0 * lv.npts, moved);
+            Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, 1, c->pp};
+#define VOF_LAUNCH_S0P(NS_, PO_)                                                                                                    \
+            do {                                                                                                                    \
+                const size_t ldsp = S0R<NS_, 0>::LDS_BYTES;                                                                         \
+                if (ecoarse) k_sweep0p<NS_, true, false, PO_><<<g, 64, ldsp, c->stream>>>(f0, lv.ni, lv.nj, TI, nx, nxp, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj); \
+                else if (!x_in) k_sweep0p<NS_, false, true, PO_><<<g, 64, ldsp, c->stream>>>(f0, lv.ni, lv.nj, TI, nx, nxp, ny, np, x_in, x_out, b, active, nullptr, 0, 0); \
+                else k_sweep0p<NS_, false, false, PO_><<<g, 64, ldsp, c->stream>>>(f0, lv.ni, lv.nj, TI, nx, nxp, ny, np, x_in, x_out, b, active, nullptr, 0, 0); \
+            } while (0)
+            if (NSW == 2) { if (po) VOF_LAUNCH_S0P(2, 1); else VOF_LAUNCH_S0P(2, 0); }
+            else { if (po) VOF_LAUNCH_S0P(1, 1); else VOF_LAUNCH_S0P(1, 0); }
+#undef VOF_LAUNCH_S0P
             return;
         }
     }
@@ -770,7 +770,8 @@ VT* smooth_level_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int nu, bool 
     }
     // out-of-place fused sweeps: choose the first destination so that the last pass writes into x.  On level 0 a pass of
     // k_sweep0m performs two sweeps (temporal blocking): nu sweeps = ceil(nu / 2) passes over the data.
-    const bool two = l == 0 && std::is_same<VT, double>::value && sweep0m_usable(c) && c->sweep0m_pairs;
+    const bool two = l == 0 && ((std::is_same<VT, double>::value && sweep0m_usable(c) && c->sweep0m_pairs) ||
+                                (std::is_same<VT, float>::value && sweep0p_usable(c) && c->sweep0m_pairs));
     const int npass = two ? (nu + 1) / 2 : nu;
     const VT* src = from_zero ? nullptr : x;
     VT* dst = (from_zero && (npass % 2 == 1)) ? x : tmp;
@@ -1354,8 +1355,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     // storage type of the cycle vectors for this batch (an earlier batch may have switched to float64: "auto"
     // precision after 8 iterations, GMRES fallback)
     c->vfloat = (P.vcycle_precision == 1 || P.vcycle_precision == 2) && c->fused && c->L.size() > 1 && !c->direct_on;
-    c->vcoarse32 = P.vcycle_precision >= 3 && !c->direct_on;
-    c->smooth32 = P.vcycle_precision == 4 && !c->direct_on;
+    c->vcoarse32 = P.vcycle_precision == 3 && !c->direct_on;
     if (c->direct_on) {   // direct preconditioner: block-tridiagonal LU instead of the Galerkin hierarchy
         if (np > c->dir_cap) { c->err = "batch larger than the direct preconditioner's buffers"; return -1; }
         c->frames = frames_dev;
@@ -1416,7 +1416,7 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         if (nact == 0) break;
         // vcycle_precision 2 ("auto"): float32 V-cycle vectors for the first iterations, float64 for stragglers
         // (in the slowly converging regimes float32 storage costs iterations)
-        if (it_total == AUTO_F64_AFTER) { if (P.vcycle_precision == 2) c->vfloat = false; c->vcoarse32 = false; c->smooth32 = false; }
+        if (it_total == AUTO_F64_AFTER) { if (P.vcycle_precision == 2) c->vfloat = false; c->vcoarse32 = false; }
         c->cur_units = nact;
         const int* act = c->active;
         void* vrhs_p = c->vfloat ? (void*)c->b32 : (void*)c->kp;   // V-cycle right-hand sides (V-typed)
@@ -1548,7 +1548,7 @@ int check_params(vof_ctx* c, const vof_params* p) {
     if (p->w_cycle_visits < 0 || p->w_cycle_visits > 8) { c->err = "w_cycle_visits must be in [0, 8]"; return -1; }
     if (!(p->rtol > 0.0)) { c->err = "rtol must be > 0"; return -1; }
     if (p->coarse_precision < 0 || p->coarse_precision > 3) { c->err = "coarse_precision must be 0, 1, 2 or 3"; return -1; }
-    if (p->vcycle_precision < 0 || p->vcycle_precision > (VOF_EXP_SWEEP0P ? 4 : 3)) { c->err = "vcycle_precision must be 0, 1, 2 or 3"; return -1; }
+    if (p->vcycle_precision < 0 || p->vcycle_precision > 3) { c->err = "vcycle_precision must be 0, 1, 2 or 3"; return -1; }
     if (p->krylov_method < 0 || p->krylov_method > 2) { c->err = "krylov_method must be 0, 1 or 2"; return -1; }
     if (p->gmres_restart < 0 || p->gmres_restart > GM_MAXM) { c->err = "gmres_restart must be in [0, 128]"; return -1; }
     if (p->fallback_after < 0) { c->err = "fallback_after must be >= 0"; return -1; }
@@ -2466,7 +2466,6 @@ int vof_bench_sweeps_dev(vof_ctx* c, const double* movie, int n_pairs, const vof
     if (n_pairs < 1 || n_pairs > c->B) { c->err = "n_pairs must be in [1, max_pairs_in_flight]"; return -1; }
     if (c->L.size() < 2) { c->err = "grid too small for the sweep benchmark"; return -1; }
     if (int rc = check_params(c, p)) return rc;
-    c->smooth32 = p->vcycle_precision == 4;
     HIPCHK(hipSetDevice(c->device));
     c->frames = movie;
     c->npairs = n_pairs;
@@ -2579,8 +2578,7 @@ int vof_debug_setup(vof_ctx* c, const double* movie_host, int n_pairs, const vof
     HIPCHK(hipMemcpyAsync(c->st_movie, movie_host, (size_t)(n_pairs + 1) * fs * sizeof(double), hipMemcpyHostToDevice,
                           c->stream));
     if (int rc = setup_batch(c, c->st_movie, n_pairs)) return rc;
-    c->vcoarse32 = p->vcycle_precision >= 3;   // vof_debug_vcycle* run the cycle as a solve would (the per-level entry points: float64)
-    c->smooth32 = p->vcycle_precision == 4;
+    c->vcoarse32 = p->vcycle_precision == 3;   // vof_debug_vcycle* run the cycle as a solve would (the per-level entry points: float64)
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }

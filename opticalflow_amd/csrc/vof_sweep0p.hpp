@@ -1,20 +1,21 @@
-// vof_sweep0p.hpp - k_sweep0p: the register-resident level-0 smoother pass (vof_sweep0r.hpp) in PACKED FLOAT32 arithmetic.
+// vof_sweep0p.hpp - k_sweep0p: the register-resident level-0 smoother pass (vof_sweep0r.hpp) for FLOAT32 cycle vectors, in
+// PACKED float32 arithmetic.
 //
-// k_sweep0r is bound by the FP64 vector pipes (measured, scripts/gpu_valu_rate.hip + profiles/r03_sq_sweep0.md: 78 FP64
-// instructions per point update at 4.1-5 cycles each, 58-61 % of all SIMD cycles busy with them, clocks at 1.7-1.8 GHz), not
-// by HBM.  The smoother is part of the PRECONDITIONER: the Krylov iteration, its operator products, the residuals and the
-// stopping rule stay float64, and the cycle vectors below level 0 are float32 already (vcycle_precision 3).  Float32
-// arithmetic in the level-0 sweeps leaves every iteration count of the well-conditioned regimes unchanged (CPU prototype
-// experiment, DESIGN.md section 3.1: N, 8-bit alpha 1e5, alpha = beta = 1, alpha 0.5, 8-bit alpha = beta = 1e6: the same
-// counts to rtol 1e-6 and 1e-10); the grad-div dominated regime T needs float64 there, which is what the solver switches
-// to after AUTO_F64_AFTER iterations anyway (together with the float64 cycle vectors).
+// k_sweep0r is bound by the FP64 vector pipes (profiles/r03_sq_sweep0.md: 78 FP64 instructions per point update at 4-5 cycles
+// each, 58-61 % of all SIMD cycles busy with them at 1.7-1.8 GHz), not by HBM.  With float32 cycle vectors
+// (vcycle_precision 1 / 2: x, b and the coarse-grid correction of the cycle are float32 in HBM; the Krylov vectors, the
+// operator products, the residuals and the stopping rule stay float64) the smoother can do its arithmetic in float32 as well:
+// it is part of the preconditioner, and float32 arithmetic there leaves the iteration counts of the well-conditioned regimes
+// unchanged (CPU prototype experiment; the grad-div dominated regimes need float64, which is what
+// the solver switches to after AUTO_F64_AFTER iterations in mode 2).
 //
-// One wave owns TWO interior strips (A, B: 2 x 128 columns) and carries them as the two halves of packed registers:
-// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process both strips in one instruction at the rate of one FP64 instruction,
-// and a DPP lane shift moves both.  Same schedule as k_sweep0r (stage st on row e - st, window rows e - 2 NS .. e + 3, image
-// rows through a wave-private LDS ring - here of float pairs {A, B}), no trailing operator stage (the Krylov product needs
-// float64 and runs as its own kernel in this mode).  The strips at the left / right side of the image (ghost columns) are
-// left to k_sweep0r: they are a fifth of the image at 1024^2.  x and b are float64 in HBM and converted on the way.
+// One wave owns TWO strips (A = strip 2 j, B = strip 2 j + 1; 2 x 128 columns) and carries them as the two halves of packed
+// registers: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process both strips in one instruction at the cost of one FP64
+// instruction, a DPP lane shift moves both, and the loads in flight are half the size of k_sweep0r's.  Same schedule as
+// k_sweep0r (stage st on row e - st, register window rows e - 2 NS .. e + 3, image rows through a wave-private LDS ring -
+// here of float pairs {A, B}), same ghost folding at the image sides and rows (per strip), no trailing operator stage (the
+// Krylov product is float64 and runs as its own kernel).  Results agree with the float64-arithmetic sweeps to float32
+// rounding (tests), not bit for bit.
 #pragma once
 #include "vof_sweep0r.hpp"
 
@@ -36,12 +37,15 @@ __device__ __forceinline__ f2 f2_shl1(f2 v) {
 }
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 f2_bc(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 f2_sel(bool ca, bool cb, f2 a, f2 b) { return f2{ca ? a.x : b.x, cb ? a.y : b.y}; }   // per strip: c ? a : b
 
 struct NbrP { f2 u[9], w[9], g[9]; };
 
-// gs0_point in packed float32 (interior points: no corner factors), reference quirk 'dy' == 'dx' built in.  Same formulas
-// as gs0_point; the 2x2 determinant is inverted with v_rcp_f32 + one Newton step.
-__device__ __forceinline__ void gs0_point_p(const f2* im, const NbrP& n, f2 alpha, f2 beta, f2 inv_g, f2 b0, f2 b1, f2 b2, f2& u, f2& w, f2& gm) {
+// gs0_point in packed float32, reference quirk 'dy' == 'dx' built in.  Same formulas as gs0_point (CORNERS: the factor 2 of
+// a corner ghost, per strip); the 2x2 determinant is inverted with v_rcp_f32 + one Newton step.
+template <bool CORNERS>
+__device__ __forceinline__ void gs0_point_p(const f2* im, const NbrP& n, f2 sUL, f2 sUR, f2 sDL, f2 sDR, f2 alpha, f2 beta, f2 inv_g, f2 b0,
+                                            f2 b1, f2 b2, f2& u, f2& w, f2& gm) {
     const f2 P = im[4];
     const f2 Dx = (im[7] - im[1]) * 0.5f;
     const f2 Dxx = f2_fma(f2_bc(-2.0f), P, im[7] + im[1]);
@@ -50,8 +54,14 @@ __device__ __forceinline__ void gs0_point_p(const f2* im, const NbrP& n, f2 alph
     const f2 PP = P * P, PDx = P * Dx, hP = P * 0.5f;
     const f2 A1 = PP + alpha, qPP = PP * 0.25f, hPDx = PDx * 0.5f;
     const f2 du71 = n.u[7] - n.u[1], du53 = n.u[5] - n.u[3], dw71 = n.w[7] - n.w[1], dw53 = n.w[5] - n.w[3];
-    const f2 W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
-    const f2 U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+    f2 W4, U4;
+    if (CORNERS) {
+        W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
+        U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+    } else {
+        W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
+        U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+    }
     const f2 y0a = f2_fma(hPDx, dw53, f2_fma(alpha, n.u[3] + n.u[5], A1 * (n.u[1] + n.u[7])));
     const f2 y0b = f2_fma(hP, n.g[1] - n.g[7], f2_fma(qPP, W4, f2_fma(hPDx, dw71, PDx * du71)));
     const f2 y1a = f2_fma(hPDx, du71, f2_fma(alpha, n.w[1] + n.w[7], A1 * (n.w[3] + n.w[5])));
@@ -70,12 +80,12 @@ __device__ __forceinline__ void gs0_point_p(const f2* im, const NbrP& n, f2 alph
 
 struct S0PRow { f2 ux, uy, wx, wy, gx, gy; };   // one x row of the two strips: ?x = column 2 lane, ?y = column 2 lane + 1
 
-// grid: (number of strip pairs) x ny x pairs blocks of one wave; strip pair j = strips bx_first + 2 j, bx_first + 2 j + 1
-template <int NS, bool EC, bool FROM_ZERO, typename ET, int PO>
+// grid: nxp (strip pairs: strips 2 j, 2 j + 1; the last pair may lack its second strip) x ny x pairs blocks of one wave
+template <int NS, bool EC, bool FROM_ZERO, int PO>
 __global__ __launch_bounds__(64) void k_sweep0p(
-    Fine0 pol, int ni, int nj, int TI, int bx_first, int nxp, int ny, int nz, const double* __restrict__ x_in,
-    double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
-    const ET* __restrict__ ecoarse, int nci, int ncj) {
+    Fine0 pol, int ni, int nj, int TI, int nx, int nxp, int ny, int nz, const float* __restrict__ x_in,
+    float* __restrict__ x_out, const float* __restrict__ b, const int* __restrict__ active,
+    const float* __restrict__ ecoarse, int nci, int ncj) {
     typedef S0R<NS, 0> G;
     constexpr int W = S0_W, LO = G::LO, NRW = G::NRW, NRI = G::NRI, IRB = G::IRB, IHB = G::IPW * 8;
     constexpr int NST = 2 * NS, po = PO;
@@ -89,22 +99,32 @@ __global__ __launch_bounds__(64) void k_sweep0p(
     if (active && !active[pair]) return;
     const int lane = threadIdx.x;
     const int p0 = by * TI - po;
-    const int qsA = (bx_first + 2 * bxp) * G::OUT - G::HALO, qsB = qsA + G::OUT;   // both strips lie inside the image: 0 <= qs, qs + 128 <= nj
+    const int qsA = (2 * bxp) * G::OUT - G::HALO, qsB = qsA + G::OUT;
+    const bool hasB = 2 * bxp + 1 < nx;                                      // (wave-uniform) the pair's second strip exists
     const size_t npts = (size_t)ni * nj, off = (size_t)pair * 3 * npts;
-    const double* xin = FROM_ZERO ? nullptr : x_in + off;
-    double* xout = x_out + off;
-    const double* bp = b + off;
+    const float* xin = FROM_ZERO ? nullptr : x_in + off;
+    float* xout = x_out + off;
+    const float* bp = b + off;
     const size_t ncpts = (size_t)nci * ncj;
-    const ET* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
+    const float* ec = EC ? ecoarse + (size_t)pair * 3 * ncpts : nullptr;
     double alpha_d = pol.alpha, beta_d = pol.beta;
     int fidx = pair;
     if (pol.pp) { alpha_d = pol.pp[pair].alpha; beta_d = pol.pp[pair].beta; fidx = pol.pp[pair].frame; }
     const double* img = pol.frames + (size_t)fidx * pol.frame_stride;
     const int Nj = pol.Nj;
     const f2 alpha = f2_bc((float)alpha_d), beta = f2_bc((float)beta_d), inv_g = f2_bc((float)(1.0 / (-1 - 4 * beta_d)));
-    const size_t qgA = (size_t)(qsA + 2 * lane), qgB = (size_t)(qsB + 2 * lane);
-    const size_t xqA = (size_t)(qsA + 128), xqB = (size_t)(qsB + 128);       // image pair 64 of a strip (columns 128, 129)
-    const bool st_ok = lane >= G::HALO / 2 && lane < (W - G::HALO) / 2;      // owned column pairs (the same lanes in both strips)
+    // per strip: lane <-> column pair (2 lane, 2 lane + 1); pair validity is all-or-nothing (qs and nj are even)
+    const int qpA = qsA + 2 * lane, qpB = qsB + 2 * lane;
+    const bool okA = qpA >= 0 && qpA + 1 < nj, okB = hasB && qpB >= 0 && qpB + 1 < nj;
+    const size_t qgA = okA ? (size_t)qpA : 0, qgB = okB ? (size_t)qpB : 0;
+    const bool iokA = qpA >= 0 && qpA + 1 <= nj + 1, iokB = hasB && qpB >= 0 && qpB + 1 <= nj + 1;   // image columns (full image)
+    const size_t iqA = iokA ? (size_t)qpA : 0, iqB = iokB ? (size_t)qpB : 0;
+    const int xqA = qsA + 128, xqB = qsB + 128;                              // image pair 64 of a strip (columns 128, 129)
+    const bool xokA = xqA >= 0 && xqA + 1 <= nj + 1, xokB = hasB && xqB >= 0 && xqB + 1 <= nj + 1;
+    const bool own = lane >= G::HALO / 2 && lane < (W - G::HALO) / 2;        // owned column pairs (the same lanes in both strips)
+    const bool stA = okA && own, stB = okB && own;
+    const bool glA = qpA == 0, glB = hasB && qpB == 0, grA = qpA + 1 == nj - 1, grB = hasB && qpB + 1 == nj - 1;   // ghost columns
+    const bool interior = qsA >= 0 && hasB && qsB + W <= nj;                 // (wave-uniform) neither strip touches a side of the image
     const int cqsA = qsA >> 1, cqsB = qsB >> 1;
 
     S0PRow X[NRW];
@@ -136,7 +156,14 @@ __global__ __launch_bounds__(64) void k_sweep0p(
 
     int islot = 0;
     auto irow = [&](int j) { int s = islot + j; if (s >= NRI) s -= NRI; return iring + s * IRB; };
-    auto pack = [](double a, double b2) { return f2{(float)a, (float)b2}; };
+    auto pack = [](float a, float b2) { return f2{a, b2}; };
+
+    // a float2 of one strip at `base + q` (steady state: unconditional)
+    auto ld2 = [](auto edge_tag, const float* base, size_t q, bool ok) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        if (EDGE && !ok) return make_float2(0.f, 0.f);
+        return *reinterpret_cast<const float2*>(base + q);
+    };
 
     auto request_rows = [&](auto edge_tag, int e) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -149,11 +176,10 @@ __global__ __launch_bounds__(64) void k_sweep0p(
             if (!FROM_ZERO) {
                 const bool rowok = EDGE ? (do_load && pL >= 0 && pL < ni) : true;
                 if (rowok) {
-                    const double* sa = xin + (size_t)pL * nj + qgA;
-                    const double* sb = xin + (size_t)pL * nj + qgB;
-                    const double2 ua = *reinterpret_cast<const double2*>(sa), ub = *reinterpret_cast<const double2*>(sb);
-                    const double2 wa = *reinterpret_cast<const double2*>(sa + npts), wb = *reinterpret_cast<const double2*>(sb + npts);
-                    const double2 ga = *reinterpret_cast<const double2*>(sa + 2 * npts), gb = *reinterpret_cast<const double2*>(sb + 2 * npts);
+                    const float* row = xin + (size_t)pL * nj;
+                    const float2 ua = ld2(edge_tag, row, qgA, okA), ub = ld2(edge_tag, row, qgB, okB);
+                    const float2 wa = ld2(edge_tag, row + npts, qgA, okA), wb = ld2(edge_tag, row + npts, qgB, okB);
+                    const float2 ga = ld2(edge_tag, row + 2 * npts, qgA, okA), gb = ld2(edge_tag, row + 2 * npts, qgB, okB);
                     d.ux = pack(ua.x, ub.x); d.uy = pack(ua.y, ub.y);
                     d.wx = pack(wa.x, wb.x); d.wy = pack(wa.y, wb.y);
                     d.gx = pack(ga.x, gb.x); d.gy = pack(ga.y, gb.y);
@@ -165,10 +191,13 @@ __global__ __launch_bounds__(64) void k_sweep0p(
                 if (EDGE) { lix_[r] = liy_[r] = lxx_[r] = lxy_[r] = f2_bc(0.f); }
                 if (rowok) {
                     const double* frow = img + (size_t)pI * Nj;
-                    const double2 ia = *reinterpret_cast<const double2*>(frow + qgA), ib = *reinterpret_cast<const double2*>(frow + qgB);
-                    const double2 xa = *reinterpret_cast<const double2*>(frow + xqA), xb = *reinterpret_cast<const double2*>(frow + xqB);
-                    lix_[r] = pack(ia.x, ib.x); liy_[r] = pack(ia.y, ib.y);
-                    lxx_[r] = pack(xa.x, xb.x); lxy_[r] = pack(xa.y, xb.y);
+                    double2 ia = {0, 0}, ib = {0, 0}, xa = {0, 0}, xb = {0, 0};
+                    if (EDGE ? iokA : true) ia = *reinterpret_cast<const double2*>(frow + iqA);
+                    if (EDGE ? iokB : true) ib = *reinterpret_cast<const double2*>(frow + iqB);
+                    if (EDGE ? xokA : true) xa = *reinterpret_cast<const double2*>(frow + (EDGE ? (xokA ? xqA : 0) : xqA));
+                    if (EDGE ? xokB : true) xb = *reinterpret_cast<const double2*>(frow + (EDGE ? (xokB ? xqB : 0) : xqB));
+                    lix_[r] = pack((float)ia.x, (float)ib.x); liy_[r] = pack((float)ia.y, (float)ib.y);
+                    lxx_[r] = pack((float)xa.x, (float)xb.x); lxy_[r] = pack((float)xa.y, (float)xb.y);
                 }
             }
         }
@@ -178,8 +207,10 @@ __global__ __launch_bounds__(64) void k_sweep0p(
             for (int f = 0; f < 3; ++f) {
                 crv[f] = f2_bc(0.f);
                 if (EDGE ? (knew >= 0 && knew < nci) : true) {
-                    const ET* er = ec + (size_t)f * ncpts + (size_t)knew * ncj;
-                    crv[f] = f2{(float)er[cqsA + lane], (float)er[cqsB + lane]};   // (interior strips: every lane's coarse column exists)
+                    const float* er = ec + (size_t)f * ncpts + (size_t)knew * ncj;
+                    const int ca = cqsA + lane, cb = cqsB + lane;
+                    if (EDGE) crv[f] = f2{(ca >= 0 && ca < ncj) ? er[ca] : 0.f, (hasB && cb >= 0 && cb < ncj) ? er[cb] : 0.f};
+                    else crv[f] = f2{er[ca], er[cb]};
                 }
             }
         }
@@ -195,11 +226,10 @@ __global__ __launch_bounds__(64) void k_sweep0p(
             for (int f = 0; f < 3; ++f) Bx[st][f] = By[st][f] = f2_bc(0.f);
         }
         if (rowok) {
-            const double* ba = bp + (size_t)p * nj + qgA;
-            const double* bb = bp + (size_t)p * nj + qgB;
+            const float* row = bp + (size_t)p * nj;
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                const double2 va = *reinterpret_cast<const double2*>(ba + (size_t)f * npts), vb = *reinterpret_cast<const double2*>(bb + (size_t)f * npts);
+                const float2 va = ld2(edge_tag, row + (size_t)f * npts, qgA, okA), vb = ld2(edge_tag, row + (size_t)f * npts, qgB, okB);
                 Bx[st][f] = pack(va.x, vb.x);
                 By[st][f] = pack(va.y, vb.y);
             }
@@ -207,7 +237,7 @@ __global__ __launch_bounds__(64) void k_sweep0p(
     };
 
     auto stage = [&](auto edge_tag, auto jc_tag, int rr, auto st_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr bool EDGE = decltype(edge_tag)::value;   // also: the strips may touch a side of the image
         constexpr int jc = decltype(jc_tag)::value;
         constexpr int st = decltype(st_tag)::value;
         const int p = p0 + rr;
@@ -232,6 +262,7 @@ __global__ __launch_bounds__(64) void k_sweep0p(
             S0PRow& RC = X[jc];
             NbrP n;
             f2 imv[9];
+            bool gla = false, glb = false, gra = false, grb = false;
             if (par == 0) {
                 n.u[1] = RU.ux; n.w[1] = RU.wx; n.g[1] = RU.gx;
                 n.u[7] = RD.ux; n.w[7] = RD.wx; n.g[7] = RD.gx;
@@ -241,6 +272,12 @@ __global__ __launch_bounds__(64) void k_sweep0p(
                 n.u[0] = f2_shr1(RU.uy); n.w[0] = f2_shr1(RU.wy);
                 n.u[3] = f2_shr1(RC.uy); n.w[3] = f2_shr1(RC.wy); n.g[3] = f2_shr1(RC.gy);
                 n.u[6] = f2_shr1(RD.uy); n.w[6] = f2_shr1(RD.wy);
+                if (EDGE) {   // ghost column -1 mirrors column 1 (per strip)
+                    gla = glA; glb = glB;
+                    n.u[0] = f2_sel(gla, glb, n.u[2], n.u[0]); n.w[0] = f2_sel(gla, glb, n.w[2], n.w[0]);
+                    n.u[3] = f2_sel(gla, glb, n.u[5], n.u[3]); n.w[3] = f2_sel(gla, glb, n.w[5], n.w[3]); n.g[3] = f2_sel(gla, glb, n.g[5], n.g[3]);
+                    n.u[6] = f2_sel(gla, glb, n.u[8], n.u[6]); n.w[6] = f2_sel(gla, glb, n.w[8], n.w[6]);
+                }
                 imv[0] = iuA; imv[1] = iuB; imv[2] = iuC; imv[3] = icA; imv[4] = icB; imv[5] = icC; imv[6] = idA; imv[7] = idB; imv[8] = idC;
             } else {
                 n.u[1] = RU.uy; n.w[1] = RU.wy; n.g[1] = RU.gy;
@@ -251,11 +288,24 @@ __global__ __launch_bounds__(64) void k_sweep0p(
                 n.u[2] = f2_shl1(RU.ux); n.w[2] = f2_shl1(RU.wx);
                 n.u[5] = f2_shl1(RC.ux); n.w[5] = f2_shl1(RC.wx); n.g[5] = f2_shl1(RC.gx);
                 n.u[8] = f2_shl1(RD.ux); n.w[8] = f2_shl1(RD.wx);
+                if (EDGE) {   // ghost column n_j mirrors column n_j - 2 (per strip)
+                    gra = grA; grb = grB;
+                    n.u[2] = f2_sel(gra, grb, n.u[0], n.u[2]); n.w[2] = f2_sel(gra, grb, n.w[0], n.w[2]);
+                    n.u[5] = f2_sel(gra, grb, n.u[3], n.u[5]); n.w[5] = f2_sel(gra, grb, n.w[3], n.w[5]); n.g[5] = f2_sel(gra, grb, n.g[3], n.g[5]);
+                    n.u[8] = f2_sel(gra, grb, n.u[6], n.u[8]); n.w[8] = f2_sel(gra, grb, n.w[6], n.w[8]);
+                }
                 imv[0] = iuB; imv[1] = iuC; imv[2] = iuD; imv[3] = icB; imv[4] = icC; imv[5] = icD; imv[6] = idB; imv[7] = idC; imv[8] = idD;
             }
             f2 u, w, gm;
-            if (par == 0) gs0_point_p(imv, n, alpha, beta, inv_g, Bx[st][0], Bx[st][1], Bx[st][2], u, w, gm);
-            else gs0_point_p(imv, n, alpha, beta, inv_g, By[st][0], By[st][1], By[st][2], u, w, gm);
+            const f2 c0 = par ? By[st][0] : Bx[st][0], c1 = par ? By[st][1] : Bx[st][1], c2 = par ? By[st][2] : Bx[st][2];
+            if (EDGE) {
+                const f2 one = f2_bc(1.f), two = f2_bc(2.f);
+                const f2 sUL = f2_sel(oU && gla, oU && glb, two, one), sUR = f2_sel(oU && gra, oU && grb, two, one);
+                const f2 sDL = f2_sel(oD && gla, oD && glb, two, one), sDR = f2_sel(oD && gra, oD && grb, two, one);
+                gs0_point_p<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, c0, c1, c2, u, w, gm);
+            } else {
+                gs0_point_p<false>(imv, n, f2_bc(1.f), f2_bc(1.f), f2_bc(1.f), f2_bc(1.f), alpha, beta, inv_g, c0, c1, c2, u, w, gm);
+            }
             if (par == 0) { RC.ux = u; RC.wx = w; RC.gx = gm; }
             else { RC.uy = u; RC.wy = w; RC.gy = gm; }
         }
@@ -277,21 +327,24 @@ __global__ __launch_bounds__(64) void k_sweep0p(
             run_stage(std::integral_constant<int, 2>{});
             run_stage(std::integral_constant<int, 3>{});
         }
-        // write-out of rows e - 2 NS, e - 2 NS + 1 (float64 in HBM)
+        // write-out of rows e - 2 NS, e - 2 NS + 1
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int rrW = e - 2 * NS + r, pW = p0 + rrW;
             const bool rowok = EDGE ? (rrW >= 0 && rrW < TI && pW >= 0 && pW < ni) : true;
-            if (rowok && st_ok) {
+            if (rowok) {
                 const S0PRow& s = X[LO - 2 * NS + r];
-                double* da = xout + (size_t)pW * nj + qgA;
-                double* db = xout + (size_t)pW * nj + qgB;
-                *reinterpret_cast<double2*>(da) = double2{(double)s.ux.x, (double)s.uy.x};
-                *reinterpret_cast<double2*>(db) = double2{(double)s.ux.y, (double)s.uy.y};
-                *reinterpret_cast<double2*>(da + npts) = double2{(double)s.wx.x, (double)s.wy.x};
-                *reinterpret_cast<double2*>(db + npts) = double2{(double)s.wx.y, (double)s.wy.y};
-                *reinterpret_cast<double2*>(da + 2 * npts) = double2{(double)s.gx.x, (double)s.gy.x};
-                *reinterpret_cast<double2*>(db + 2 * npts) = double2{(double)s.gx.y, (double)s.gy.y};
+                float* row = xout + (size_t)pW * nj;
+                if (stA) {
+                    *reinterpret_cast<float2*>(row + qgA) = make_float2(s.ux.x, s.uy.x);
+                    *reinterpret_cast<float2*>(row + npts + qgA) = make_float2(s.wx.x, s.wy.x);
+                    *reinterpret_cast<float2*>(row + 2 * npts + qgA) = make_float2(s.gx.x, s.gy.x);
+                }
+                if (stB) {
+                    *reinterpret_cast<float2*>(row + qgB) = make_float2(s.ux.y, s.uy.y);
+                    *reinterpret_cast<float2*>(row + npts + qgB) = make_float2(s.wx.y, s.wy.y);
+                    *reinterpret_cast<float2*>(row + 2 * npts + qgB) = make_float2(s.gx.y, s.gy.y);
+                }
             }
         }
         {   // the image rows in flight take the ring slots of rows e - LO, e - LO + 1
@@ -311,7 +364,7 @@ __global__ __launch_bounds__(64) void k_sweep0p(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (EC) {   // x + P e for the rows that enter (as k_sweep0r; float32 here)
+        if constexpr (EC) {   // x + P e for the rows that enter (terms as in k_prolong_add; float32 here)
             const int pL0 = p0 + e + 2;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -320,7 +373,8 @@ __global__ __launch_bounds__(64) void k_sweep0p(
                 if (rowok) {
                     const int cp = pL >> 1;
                     const bool ipi = EDGE ? ((pL & 1) && (cp + 1 < nci)) : (((PO + r) & 1) != 0);
-                    // (interior strips: the odd column always has its right coarse neighbour)
+                    // per strip: the odd column has a right coarse neighbour (steady state: always)
+                    const bool ipjA = EDGE ? ((qpA >> 1) + 1 < ncj) : true, ipjB = EDGE ? ((qpB >> 1) + 1 < ncj) : true;
                     const int i0 = cp - (pL0 >> 1);
                     S0PRow& d = X[LO + 2 + r];
 #pragma unroll
@@ -329,15 +383,20 @@ __global__ __launch_bounds__(64) void k_sweep0p(
                         const f2 a1 = i0 ? crv[f] : CR[1][f];
                         const f2 a0r = f2_shl1(a0), a1r = f2_shl1(a1);
                         const float wi0 = ipi ? 0.5f : 1.0f;
+                        const f2 wj0 = f2_sel(ipjA, ipjB, f2_bc(0.5f), f2_bc(1.0f)), wj1 = f2_sel(ipjA, ipjB, f2_bc(0.5f), f2_bc(0.0f));
                         f2 ve = a0 * wi0;
-                        f2 vo = a0 * (wi0 * 0.5f) + a0r * (wi0 * 0.5f);
+                        f2 vo = a0 * (wj0 * wi0) + a0r * (wj1 * wi0);
                         if (ipi) {
                             ve += a1 * 0.5f;
-                            vo += a1 * 0.25f + a1r * 0.25f;
+                            vo += a1 * (wj0 * 0.5f) + a1r * (wj1 * 0.5f);
                         }
                         if (f == 0) { d.ux += ve; d.uy += vo; }
                         else if (f == 1) { d.wx += ve; d.wy += vo; }
                         else { d.gx += ve; d.gy += vo; }
+                    }
+                    if (EDGE) {   // keep the columns outside the image at zero
+                        if (!okA) { d.ux.x = d.uy.x = d.wx.x = d.wy.x = d.gx.x = d.gy.x = 0.f; }
+                        if (!okB) { d.ux.y = d.uy.y = d.wx.y = d.wy.y = d.gx.y = d.gy.y = 0.f; }
                     }
                 }
             }
@@ -360,15 +419,16 @@ __global__ __launch_bounds__(64) void k_sweep0p(
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                const int k = k0 + d;
+                const int k = k0 + d, ca = cqsA + lane, cb = cqsB + lane;
                 const bool rowok = k >= 0 && k < nci;
-                const ET* er = ec + (size_t)f * ncpts + (size_t)(rowok ? k : 0) * ncj;
-                CR[d][f] = rowok ? f2{(float)er[cqsA + lane], (float)er[cqsB + lane]} : f2_bc(0.f);
+                const float* er = ec + (size_t)f * ncpts + (size_t)(rowok ? k : 0) * ncj;
+                CR[d][f] = f2{(rowok && ca >= 0 && ca < ncj) ? er[ca] : 0.f, (rowok && hasB && cb >= 0 && cb < ncj) ? er[cb] : 0.f};
             }
     }
     for (int s = s_first; s <= s_last; ++s) {
         const int e = 2 * s;
-        if (e >= e_lo && e <= e_hi) step(std::false_type{}, e);
+        // (strip pairs that touch a side of the image run the edge version throughout)
+        if (e >= e_lo && e <= e_hi && interior) step(std::false_type{}, e);
         else step(std::true_type{}, e);
     }
 }

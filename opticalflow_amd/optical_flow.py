@@ -171,7 +171,7 @@ def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x
         initial_remodelling=float(initial_remodelling), rtol=float(rtol), max_iterations=int(max_iterations),
         reference_quirks=int(bool(reference_quirks)),
         coarse_precision={"float64": 0, "float32": 1, "bfloat16": 2, "float8": 3}[coarse_precision],
-        vcycle_precision={"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3, "smoother_float32": 4}[vcycle_precision])
+        vcycle_precision={"float64": 0, "float32": 1, "auto": 2, "coarse_float32": 3}[vcycle_precision])
     if multigrid_sweeps is not None:     # (pre, post) on level 0 [, (pre, post) on the coarse levels]
         ms = tuple(int(v) for v in multigrid_sweeps)
         params.nu_pre, params.nu_post = ms[0], ms[1]
