@@ -12,6 +12,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Fault diagnosis (VOF_TEST_STDERR_FILE=path): a GPU memory fault ends the process inside the HIP runtime, and the runtime's
+    # own message (faulting address) goes to file descriptor 2, which pytest has pointed at a capture file that dies with the
+    # process.  With the variable set, fd 2 is pointed at a file that survives; the current test id is appended per test.
+    path = os.environ.get("VOF_TEST_STDERR_FILE")
+    if path:
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+        os.dup2(fd, 2)
+        os.close(fd)
+
+
+def pytest_runtest_logstart(nodeid, location):
+    if os.environ.get("VOF_TEST_STDERR_FILE"):
+        os.write(2, f"[test] {nodeid}\n".encode())
 
 
 def load_golden(name):
