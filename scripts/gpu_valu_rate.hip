@@ -6,6 +6,30 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+typedef float pf2 __attribute__((ext_vector_type(2)));
+template <int ILP, int DEP>
+__global__ __launch_bounds__(64) void kpk(double* out, int iters, double seed) {   // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+    pf2 a[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) a[i] = pf2{(float)seed + threadIdx.x + i, (float)seed - i};
+    const pf2 m = pf2{1.0000001f, 0.9999999f}, c = pf2{1e-9f, 2e-9f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int i = 0; i < ILP; ++i) {
+                if (DEP == 0) a[i] = __builtin_elementwise_fma(a[i], m, c);
+                else if (DEP == 1) a[i] = a[i] * m;
+                else a[i] = a[i] + c;
+            }
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += a[i].x + a[i].y;
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+
 template <int KIND, int ILP>
 __global__ __launch_bounds__(64) void k(double* out, int iters, double seed) {
     double a[ILP];
@@ -64,7 +88,35 @@ int run(const char* name, int waves_per_simd, int per_elem) {
     return 0;
 }
 
+template <int ILP, int DEP>
+int runpk(const char* name, int waves_per_simd) {
+    hipDeviceProp_t p;
+    CHECK(hipGetDeviceProperties(&p, 0));
+    const int cus = p.multiProcessorCount, blocks = cus * 4 * waves_per_simd, iters = 20000;
+    double* out;
+    CHECK(hipMalloc(&out, (size_t)blocks * 64 * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    kpk<ILP, DEP><<<blocks, 64>>>(out, 100, 1.0);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    kpk<ILP, DEP><<<blocks, 64>>>(out, iters, 1.0);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double ns = ms * 1e6 / ((double)iters * 16 * ILP * waves_per_simd);
+    printf("%-28s ILP %d, %d wave(s)/SIMD: %7.2f ms, %6.2f ns per wave instruction and SIMD = %5.2f cycles at the nominal 2400 MHz\n", name, ILP, waves_per_simd, ms, ns, ns * 2.4);
+    hipFree(out);
+    return 0;
+}
+
 int main() {
+    runpk<8, 0>("v_pk_fma_f32 independent", 1);
+    runpk<8, 0>("v_pk_fma_f32 independent", 2);
+    runpk<1, 0>("v_pk_fma_f32 dependent", 1);
+    runpk<8, 1>("v_pk_mul_f32 independent", 1);
+    runpk<8, 2>("v_pk_add_f32 independent", 1);
     run<0, 1>("v_fma_f64 dependent", 1, 1);
     run<0, 8>("v_fma_f64 independent", 1, 1);
     run<0, 8>("v_fma_f64 independent", 2, 1);
