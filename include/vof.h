@@ -52,7 +52,9 @@ typedef struct vof_params {
                                   bytes); 0: float64 */
     int32_t vcycle_precision;  /* storage of the V-cycle vectors: 0 float64; 1 float32; 2 auto = float32 for the first 8
                                   iterations, float64 afterwards; 3 (default) = float64 on level 0, float32 on the levels below
-                                  for the first 8 iterations (arithmetic, Krylov vectors and stopping rule always FP64) */
+                                  for the first 8 iterations.  Krylov vectors, operator products, residuals and the stopping rule are
+                                  always FP64; so is the arithmetic of every cycle kernel, except the level-0 smoother of the
+                                  float32-vector modes 1 / 2 (k_sweep0p: packed float32 - part of the preconditioner only) */
     int32_t nu_pre_coarse;     /* sweeps on the levels >= 1 (default 1); 0 = same as nu_pre / nu_post */
     int32_t nu_post_coarse;
     int32_t w_cycle_level;     /* l >= 0 (default 1): level l visits level l+1 w_cycle_visits times per cycle (a one-level W-cycle); -1: V-cycle */
@@ -69,10 +71,11 @@ typedef struct vof_params {
                                   (the reference warm-starts pair k from pair k-1, OF.py:803-806).  Default 3; 0 or 1: every pair
                                   starts from the constant initial fields.  Same stopping rule either way */
     int32_t preconditioner;    /* 0: multigrid cycle only; 1: direct - block-tridiagonal LU of the level-0 operator by image rows
-                                  (dense 3 n_j x 3 n_j Schur blocks, rocSOLVER; n_i (3 n_j)^2 doubles per pair in flight), the
+                                  (dense 3 n_j x 3 n_j Schur blocks inverted in-house; n_i (3 n_j)^2 doubles per pair in flight), the
                                   reference's SuperLU branch (OF.py:1146-1147) as the preconditioner of the same Krylov iteration;
-                                  2 (default): the multigrid cycle, and the pairs it leaves unconverged once more with the direct
-                                  preconditioner when its buffers fit into the free device memory */
+                                  2 (default): the multigrid cycle (at most 150 Krylov steps where the direct re-solve takes
+                                  seconds: images up to ~530 pixels wide), and the pairs it leaves unconverged once more with the
+                                  direct preconditioner when its buffers fit into the free device memory */
     int32_t reserved0;         /* keeps the size a multiple of 8; must be 0 */
 } vof_params;
 
@@ -114,13 +117,18 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *   VOF_FUSE_RESTRICT=0        level 0: separate residual and restriction kernels
  *   VOF_FUSE_PROLONG=0         level 0: separate prolongation kernel instead of interpolating inside the first post-sweep
  *   VOF_SWEEP0=0               level 0: the generic fused sweep kernel instead of the dedicated k_sweep0
- *   VOF_DIRECT_LU=own|rocsolver  direct preconditioner: dense inverse of the Schur blocks by the built-in kernel / by rocSOLVER
- *                              (default: built-in up to 640 unknowns per image row, rocSOLVER - loaded on first use - beyond)
- *   VOF_ROCSOLVER_LIB=path     rocSOLVER library to load
+ *   VOF_DIRECT_LU=own|blocked|rocsolver  direct preconditioner: dense inverse of the Schur blocks by the one-workgroup kernel / the
+ *                              blocked inverse on the matrix cores / rocSOLVER (default: own up to 192 unknowns per image row,
+ *                              blocked beyond; rocSOLVER only when asked for here - an A/B reference, loaded with dlopen)
+ *   VOF_ROCSOLVER_LIB=path     rocSOLVER library to load (VOF_DIRECT_LU=rocsolver only)
  *   VOF_FUSE_APPLY=0           the Krylov product after a cycle: separate operator kernel instead of the trailing stage of the
  *                              cycle's last smoothing pass
  *   VOF_SWEEP0M=0|1            level 0, float64 vectors: 0 = the 4-wave kernel k_sweep0; 1 = k_sweep0m with one sweep per pass
  *                              (default: k_sweep0m, two sweeps per pass)
+ *   VOF_SWEEP0R=0              level 0, float64 vectors: the LDS-ring pass k_sweep0m instead of the register-resident k_sweep0r
+ *   VOF_SWEEP0R_MIN_BLOCKS=n   ... k_sweep0r from n one-wave blocks per launch on (default 512; smaller launches use k_sweep0m)
+ *   VOF_SWEEP0P=0              level 0, float32 vectors: k_sweep0 (float64 arithmetic) instead of the packed-float32 k_sweep0p
+ *   VOF_PRECOND_QUIRKS=hs      experiment: hierarchy (h) / smoother (s) of the preconditioner with (1) or without (0) the 'dy' == 'dx' quirk
  *   VOF_COARSEST_MAX=3..9      coarsen until max(n_i, n_j) <= this (default 5); changes the hierarchy depth, hence iteration counts
  *   VOF_COARSE_TAIL=0          levels whose whole grid fits one workgroup: one launch per operation instead of the fused
  *                              LDS-resident coarse-tail kernel

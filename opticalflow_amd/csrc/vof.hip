@@ -153,6 +153,7 @@ struct vof_ctx {
     bool sweep0m = true;        // level 0, float64 vectors, even n_j: k_sweep0m (VOF_SWEEP0M=0: k_sweep0)
     bool sweep0m_pairs = true;  // ... two sweeps per pass (VOF_SWEEP0M=1: one sweep per pass)
     bool sweep0r = true;        // ... the register-resident pass k_sweep0r (VOF_SWEEP0R=0: the LDS-ring pass k_sweep0m)
+    long sweep0r_min_blocks = 512;   // ... for launches of at least this many one-wave blocks (VOF_SWEEP0R_MIN_BLOCKS; the tests set 0)
     bool sweep0p = true;        // level 0, float32 cycle vectors (vcycle_precision 1 / 2): the packed-float32 register-resident pass
                                 // k_sweep0p, two sweeps per pass (VOF_SWEEP0P=0: the LDS-ring kernel k_sweep0 with float64 arithmetic)
     bool tail_enabled = true;   // fused LDS-resident coarse-tail kernel (VOF_COARSE_TAIL=0: one launch per operation)
@@ -651,7 +652,9 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0r<NS_, false, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
-            if (c->sweep0r && f0.quirks) {   // (the register-resident pass is compiled with the reference's derivative quirk built in)
+            // (the register-resident pass is compiled with the reference's derivative quirk built in; one wave per block needs
+            // a few waves per SIMD-slot to fill the chip: tiny stacks - 128 x 128 x 8: 14 blocks - stay with the 4-wave LDS pass)
+            if (c->sweep0r && f0.quirks && (long)nx * ny * std::max(1, c->cur_units) >= c->sweep0r_min_blocks) {
                 if (NSW == 2) { if (po) VOF_LAUNCH_S0R(2, 1); else VOF_LAUNCH_S0R(2, 0); }
                 else { if (po) VOF_LAUNCH_S0R(1, 1); else VOF_LAUNCH_S0R(1, 0); }
             }
@@ -1716,6 +1719,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_FUSE_APPLY")) c->trail_enabled = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0R")) c->sweep0r = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0P")) c->sweep0p = e[0] != '0';
+    if (const char* e = getenv("VOF_SWEEP0R_MIN_BLOCKS")) c->sweep0r_min_blocks = atol(e);
     if (const char* e = getenv("VOF_SWEEP0M")) { c->sweep0m = e[0] != '0'; c->sweep0m_pairs = e[0] != '0' && e[0] != '1'; }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;

@@ -15,9 +15,18 @@ def relerr(a, b):
 
 @pytest.fixture(scope="module")
 def native():
+    import os
     from opticalflow_amd import _native
     _native.load_library()
-    return _native
+    # the register-resident level-0 pass k_sweep0r is the default from 512 one-wave blocks per launch on; the small grids of this
+    # file must run it too (reference_quirks=0 cases run the LDS pass k_sweep0m, so both are covered)
+    old = os.environ.get("VOF_SWEEP0R_MIN_BLOCKS")
+    os.environ["VOF_SWEEP0R_MIN_BLOCKS"] = "0"
+    yield _native
+    if old is None:
+        os.environ.pop("VOF_SWEEP0R_MIN_BLOCKS", None)
+    else:
+        os.environ["VOF_SWEEP0R_MIN_BLOCKS"] = old
 
 
 def make_case(kind, shape, npairs, seed):
