@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--w-cycle-level", type=int, default=None, help="-1: V-cycle; l: level l visits level l+1 several times")
     ap.add_argument("--w-cycle-visits", type=int, default=None)
     ap.add_argument("--warm-start-stride", type=int, default=None, help="0/1: every pair starts from the constant initial fields (library default: 3)")
+    ap.add_argument("--krylov-method", type=int, default=None, help="0 BiCGStab only, 1 restarted GMRES only, 2 (library default) BiCGStab with GMRES fallback")
     ap.add_argument("--wobble", type=float, default=0.0, help="time-varying flow of the synthetic stack (0: uniform translation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational variant runs")
@@ -228,6 +229,8 @@ def main():
         params.w_cycle_visits = args.w_cycle_visits
     if args.warm_start_stride is not None:
         params.warm_start_stride = args.warm_start_stride
+    if args.krylov_method is not None:
+        params.krylov_method = args.krylov_method
     coarse_bytes = {"float64": 8.0, "float32": 4.0, "bfloat16": 45 * 4 / 81.0, "float8": 30 * 4 / 81.0}[args.coarse_precision]   # per coefficient
 
     def step(pv=None, mv=None):
