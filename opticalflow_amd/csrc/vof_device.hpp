@@ -321,7 +321,12 @@ __device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double 
 // division, and the division by the constant -1 - 4 beta is a multiplication by its reciprocal `inv_g`: a smoother
 // needs neither to be correctly rounded, and the two divisions were a quarter of the update's instructions.
 // ------------------------------------------------------------------------------------------
-template <bool CORNERS>
+// ZERO: which neighbours are known to be zero (a sweep from a zero guess in the forward / reverse colour order meets non-zero
+// neighbours only where an earlier colour of the same sweep has been): 0 none; 1 all eight (first colour: x = D^-1 b); 2 the rows
+// above and below incl. the corners (second colour: only left / right); 3 left / right (third colour).  The reduced formulas
+// are the full ones with those operands set to zero - products with zero and additions of zero dropped -, i.e. the same bits
+// (up to the sign of an exact zero); the entries of `n` that are known to be zero are not read.
+template <bool CORNERS, int ZERO = 0>
 __device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
                                           double alpha, double beta, double inv_g, int quirks, double b0, double b1,
                                           double b2, double& u, double& w, double& gm) {
@@ -336,22 +341,44 @@ __device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double
     const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;        // OF.py:700-701
     const double PP = P * P, PDx = P * Dx, PDy = P * Dy, hP = 0.5 * P;
     const double A1 = PP + alpha, qPP = 0.25 * PP, hPDx = 0.5 * PDx, hPDy = 0.5 * PDy;
-    const double du71 = n.u[7] - n.u[1], du53 = n.u[5] - n.u[3], dw71 = n.w[7] - n.w[1], dw53 = n.w[5] - n.w[3];
-    double W4, U4;
-    if (CORNERS) {   // products with 1 or 2 are exact: same bits as the plain sums wherever no corner ghost is involved
-        W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
-        U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+    double r0, r1, r2;
+    if (ZERO == 1) {            // no non-zero neighbour
+        r0 = b0; r1 = b1; r2 = b2;
+    } else if (ZERO == 2) {     // only the left / right neighbours (indices 3, 5)
+        const double du53 = n.u[5] - n.u[3], dw53 = n.w[5] - n.w[3];
+        const double y0a = fma(hPDx, dw53, alpha * (n.u[3] + n.u[5]));
+        const double y1a = A1 * (n.w[3] + n.w[5]);
+        const double y1b = fma(hP, n.g[3] - n.g[5], fma(hPDx, du53, PDy * dw53));
+        const double y2 = fma(hP, dw53, beta * (n.g[3] + n.g[5]));
+        r0 = b0 - y0a; r1 = b1 - (y1a + y1b); r2 = b2 - y2;
     } else {
-        W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
-        U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+        const double du71 = n.u[7] - n.u[1], dw71 = n.w[7] - n.w[1];
+        double W4, U4;
+        if (CORNERS) {   // products with 1 or 2 are exact: same bits as the plain sums wherever no corner ghost is involved
+            W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
+            U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+        } else {
+            W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
+            U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+        }
+        if (ZERO == 3) {        // everything but the left / right neighbours
+            const double y0a = A1 * (n.u[1] + n.u[7]);
+            const double y0b = fma(hP, n.g[1] - n.g[7], fma(qPP, W4, fma(hPDy, dw71, PDx * du71)));
+            const double y1a = fma(hPDy, du71, alpha * (n.w[1] + n.w[7]));
+            const double y1b = qPP * U4;
+            const double y2 = fma(hP, du71, beta * (n.g[1] + n.g[7]));
+            r0 = b0 - (y0a + y0b); r1 = b1 - (y1a + y1b); r2 = b2 - y2;
+        } else {
+            const double du53 = n.u[5] - n.u[3], dw53 = n.w[5] - n.w[3];
+            // off-diagonal part of A x (OF.py:843-960 with the ghost couplings folded), two partial sums per row
+            const double y0a = fma(hPDx, dw53, fma(alpha, n.u[3] + n.u[5], A1 * (n.u[1] + n.u[7])));
+            const double y0b = fma(hP, n.g[1] - n.g[7], fma(qPP, W4, fma(hPDy, dw71, PDx * du71)));
+            const double y1a = fma(hPDy, du71, fma(alpha, n.w[1] + n.w[7], A1 * (n.w[3] + n.w[5])));
+            const double y1b = fma(hP, n.g[3] - n.g[5], fma(qPP, U4, fma(hPDx, du53, PDy * dw53)));
+            const double y2 = fma(hP, du71 + dw53, beta * ((n.g[1] + n.g[7]) + (n.g[3] + n.g[5])));
+            r0 = b0 - (y0a + y0b); r1 = b1 - (y1a + y1b); r2 = b2 - y2;
+        }
     }
-    // off-diagonal part of A x (OF.py:843-960 with the ghost couplings folded), two partial sums per row
-    const double y0a = fma(hPDx, dw53, fma(alpha, n.u[3] + n.u[5], A1 * (n.u[1] + n.u[7])));
-    const double y0b = fma(hP, n.g[1] - n.g[7], fma(qPP, W4, fma(hPDy, dw71, PDx * du71)));
-    const double y1a = fma(hPDy, du71, fma(alpha, n.w[1] + n.w[7], A1 * (n.w[3] + n.w[5])));
-    const double y1b = fma(hP, n.g[3] - n.g[5], fma(qPP, U4, fma(hPDx, du53, PDy * dw53)));
-    const double y2 = fma(hP, du71 + dw53, beta * ((n.g[1] + n.g[7]) + (n.g[3] + n.g[5])));
-    const double r0 = b0 - (y0a + y0b), r1 = b1 - (y1a + y1b), r2 = b2 - y2;
     // diagonal block [[axx, c, 0], [c, ayy, 0], [Dx, Dy, -1 - 4 beta]]: 2x2 solve, then back-substitution
     const double m4a = -4.0 * alpha;
     const double axx = fma(P, fma(-2.0, P, Dxx), m4a), ayy = fma(P, fma(-2.0, P, Dyy), m4a), c = P * Dxy;

@@ -235,33 +235,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         for (int ph = 0; ph < 2; ++ph) {
             constexpr int par_of_ph[2] = {po, 1 - po};
             const int par = par_of_ph[ph];            // column parity of this phase (compile time after unrolling)
+            // a pass FROM ZERO knows which neighbours its first sweep can meet (gs0_point's ZERO): stage 0 = first row colour pair,
+            // stage 1 = second; phase 0 / 1 = first / second colour of the row
+            constexpr int stg = LO - jc;
+            const int zero_of[2][2] = {{1, 2}, {3, 0}};
+            const int ZM = (FROM_ZERO && stg < 2) ? zero_of[stg][ph] : 0;
+            const bool needUD = ZM == 0 || ZM == 3, needLR = ZM == 0 || ZM == 2;
             S0RRow& RC = X[jc];
-            Nbr n;
+            Nbr n = {};       // (entries known to be zero are neither fetched nor read)
             double imv[9];
             bool gl = false, gr = false;
             if (par == 0) {   // even columns: left neighbour = odd column of lane - 1, right neighbour = the lane's odd column
-                n.u[1] = RU.u.x; n.w[1] = RU.w.x; n.g[1] = RU.g.x;
-                n.u[7] = RD.u.x; n.w[7] = RD.w.x; n.g[7] = RD.g.x;
-                n.u[2] = RU.u.y; n.w[2] = RU.w.y;
-                n.u[5] = RC.u.y; n.w[5] = RC.w.y; n.g[5] = RC.g.y;
-                n.u[8] = RD.u.y; n.w[8] = RD.w.y;
-                n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
-                n.u[3] = lane_shr1(RC.u.y); n.w[3] = lane_shr1(RC.w.y); n.g[3] = lane_shr1(RC.g.y);
-                n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
+                if (needUD) {
+                    n.u[1] = RU.u.x; n.w[1] = RU.w.x; n.g[1] = RU.g.x;
+                    n.u[7] = RD.u.x; n.w[7] = RD.w.x; n.g[7] = RD.g.x;
+                    n.u[2] = RU.u.y; n.w[2] = RU.w.y;
+                    n.u[8] = RD.u.y; n.w[8] = RD.w.y;
+                    n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
+                    n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
+                }
+                if (needLR) {
+                    n.u[5] = RC.u.y; n.w[5] = RC.w.y; n.g[5] = RC.g.y;
+                    n.u[3] = lane_shr1(RC.u.y); n.w[3] = lane_shr1(RC.w.y); n.g[3] = lane_shr1(RC.g.y);
+                }
                 if (BORDER && glE) {   // ghost column -1 mirrors column 1
                     gl = true;
                     n.u[0] = n.u[2]; n.w[0] = n.w[2]; n.u[3] = n.u[5]; n.w[3] = n.w[5]; n.g[3] = n.g[5]; n.u[6] = n.u[8]; n.w[6] = n.w[8];
                 }
                 imv[0] = iuA; imv[1] = iuB; imv[2] = iuC; imv[3] = icA; imv[4] = icB; imv[5] = icC; imv[6] = idA; imv[7] = idB; imv[8] = idC;
             } else {          // odd columns: left neighbour = the lane's even column, right neighbour = even column of lane + 1
-                n.u[1] = RU.u.y; n.w[1] = RU.w.y; n.g[1] = RU.g.y;
-                n.u[7] = RD.u.y; n.w[7] = RD.w.y; n.g[7] = RD.g.y;
-                n.u[0] = RU.u.x; n.w[0] = RU.w.x;
-                n.u[3] = RC.u.x; n.w[3] = RC.w.x; n.g[3] = RC.g.x;
-                n.u[6] = RD.u.x; n.w[6] = RD.w.x;
-                n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
-                n.u[5] = lane_shl1(RC.u.x); n.w[5] = lane_shl1(RC.w.x); n.g[5] = lane_shl1(RC.g.x);
-                n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
+                if (needUD) {
+                    n.u[1] = RU.u.y; n.w[1] = RU.w.y; n.g[1] = RU.g.y;
+                    n.u[7] = RD.u.y; n.w[7] = RD.w.y; n.g[7] = RD.g.y;
+                    n.u[0] = RU.u.x; n.w[0] = RU.w.x;
+                    n.u[6] = RD.u.x; n.w[6] = RD.w.x;
+                    n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
+                    n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
+                }
+                if (needLR) {
+                    n.u[3] = RC.u.x; n.w[3] = RC.w.x; n.g[3] = RC.g.x;
+                    n.u[5] = lane_shl1(RC.u.x); n.w[5] = lane_shl1(RC.w.x); n.g[5] = lane_shl1(RC.g.x);
+                }
                 if (BORDER && grO) {   // ghost column n_j mirrors column n_j - 2
                     gr = true;
                     n.u[2] = n.u[0]; n.w[2] = n.w[0]; n.u[5] = n.u[3]; n.w[5] = n.w[3]; n.g[5] = n.g[3]; n.u[8] = n.u[6]; n.w[8] = n.w[6];
@@ -270,13 +284,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             }
             const double c0 = par ? bs0.y : bs0.x, c1 = par ? bs1.y : bs1.x, c2 = par ? bs2.y : bs2.x;
             double u, w, gm;
-            if (EDGE) {
-                const double sUL = (oU && gl) ? 2.0 : 1.0, sUR = (oU && gr) ? 2.0 : 1.0;
-                const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
-                gs0_point<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
-            } else {
-                gs0_point<false>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
-            }
+            auto update = [&](auto zero_tag) {
+                constexpr int Z = decltype(zero_tag)::value;
+                if (EDGE) {
+                    const double sUL = (oU && gl) ? 2.0 : 1.0, sUR = (oU && gr) ? 2.0 : 1.0;
+                    const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
+                    gs0_point<true, Z>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
+                } else {
+                    gs0_point<false, Z>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
+                }
+            };
+            if (ZM == 1) update(std::integral_constant<int, 1>{});
+            else if (ZM == 2) update(std::integral_constant<int, 2>{});
+            else if (ZM == 3) update(std::integral_constant<int, 3>{});
+            else update(std::integral_constant<int, 0>{});
             if (par == 0) { RC.u.x = u; RC.w.x = w; RC.g.x = gm; }
             else { RC.u.y = u; RC.w.y = w; RC.g.y = gm; }
         }
