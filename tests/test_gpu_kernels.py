@@ -452,3 +452,28 @@ def test_krylov_product_fused_into_the_last_smoothing_pass(native, shape, npairs
         for k in range(npairs):
             assert dots[k, 0] == pytest.approx(float(np.vdot(v_ref[k], r[k])), rel=1e-11, abs=1e-9 * np.linalg.norm(v_ref[k]) * np.linalg.norm(r[k]))
             assert dots[k, 1] == pytest.approx(float(np.vdot(v_ref[k], v_ref[k])), rel=1e-12)
+
+
+def test_debug_switches_guard_regions_poison_and_batch_time(native, monkeypatch):
+    """Fault-attribution switches (include/vof.h): with guard regions around every device buffer, poisoned (0xFF) allocations and
+    a synchronisation + error check after every launch scope, a solve gives the same answer as without them, no guard region is
+    touched (vof_debug_check_canaries) and nothing reads uninitialised workspace (the poison is NaN: the result stays finite).
+    Also: vof_pair_stats carries the batch time."""
+    mv = make_case("texture", (66, 66), 3, 3)
+    p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9)
+    with native.Solver(66, 66, 3) as s:
+        ref = s.solve_host(mv, p)
+    for k in ("VOF_DEBUG_SYNC", "VOF_DEBUG_CANARY", "VOF_DEBUG_POISON"):
+        monkeypatch.setenv(k, "1")
+    with native.Solver(66, 66, 3) as s:
+        got = s.solve_host(mv, p)
+        s.check_canaries()
+        s.debug_setup(mv, p)                      # the debug entry points run under the same checks
+        x = np.random.default_rng(0).standard_normal((3, 3, 64, 64))
+        assert np.isfinite(s.debug_apply(0, x)).all()
+        s.check_canaries()
+    for a, b in zip(got[:4], ref[:4]):
+        np.testing.assert_array_equal(a, b)
+    st = got[4]
+    assert st["converged"].all() and np.isfinite(st["relative_residual"]).all()
+    assert (st["batch_pairs"] == 3).all() and (st["batch_ms"] > 0).all() and np.ptp(st["batch_ms"]) == 0
