@@ -643,7 +643,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             } while (0)
 #define VOF_LAUNCH_S0R(NS_, PO_)                                                                                                   \
             do {                                                                                                                    \
-                const size_t ldsr = trail ? S0R<NS_, 1>::LDS_BYTES : S0R<NS_, 0>::LDS_BYTES;                                       \
+                const size_t ldsr = trail ? S0R<NS_, 1>::LDS_TOTAL : S0R<NS_, 0>::LDS_TOTAL;                                         \
                 if (trail && ecoarse && ec32) k_sweep0r<NS_, true, false, 1, float, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr); \
                 else if (ecoarse && ec32) k_sweep0r<NS_, true, false, 0, float, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, (const float*)ecoarse, nci, ncj, tr); \
                 else if (trail && ecoarse) k_sweep0r<NS_, true, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \

@@ -326,19 +326,20 @@ __device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double 
 // above and below incl. the corners (second colour: only left / right); 3 left / right (third colour).  The reduced formulas
 // are the full ones with those operands set to zero - products with zero and additions of zero dropped -, i.e. the same bits
 // (up to the sign of an exact zero); the entries of `n` that are known to be zero are not read.
-template <bool CORNERS, int ZERO = 0>
+// DC: the image-derived diagonal block and the inverse of its 2 x 2 determinant (a third of the update's instructions) can be
+// handed on from one sweep of a pass to the next: 1 = also store them to *dg, 2 = take them from *dg instead of computing them
+// (the same values by the same operations: the same bits; only im[1], im[4], im[7] - and im[3], im[5] without the quirk - are read).
+struct Diag0 { double axx, ayy, c, inv; };
+template <bool CORNERS, int ZERO = 0, int DC = 0>
 __device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
                                           double alpha, double beta, double inv_g, int quirks, double b0, double b1,
-                                          double b2, double& u, double& w, double& gm) {
+                                          double b2, double& u, double& w, double& gm, Diag0* dg = nullptr) {
     // Every fused multiply-add is written out and automatic contraction is off: the compiler's own fusion choices depend
     // on the surrounding code, and the per-colour kernel and the streaming kernel must round identically.
 #pragma clang fp contract(off)
     const double P = im[4];
     const double Dx = (im[7] - im[1]) * 0.5;                          // OF.py:696-697
     const double Dy = quirks ? Dx : (im[5] - im[3]) * 0.5;            // OF.py:698-699 ('dy' returns the x-derivative)
-    const double Dxx = fma(-2.0, P, im[7] + im[1]);                   // OF.py:702-703
-    const double Dyy = fma(-2.0, P, im[5] + im[3]);                   // OF.py:704-705
-    const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;        // OF.py:700-701
     const double PP = P * P, PDx = P * Dx, PDy = P * Dy, hP = 0.5 * P;
     const double A1 = PP + alpha, qPP = 0.25 * PP, hPDx = 0.5 * PDx, hPDy = 0.5 * PDy;
     double r0, r1, r2;
@@ -380,12 +381,21 @@ __device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double
         }
     }
     // diagonal block [[axx, c, 0], [c, ayy, 0], [Dx, Dy, -1 - 4 beta]]: 2x2 solve, then back-substitution
-    const double m4a = -4.0 * alpha;
-    const double axx = fma(P, fma(-2.0, P, Dxx), m4a), ayy = fma(P, fma(-2.0, P, Dyy), m4a), c = P * Dxy;
-    const double det = fma(axx, ayy, -(c * c));
-    double inv = __builtin_amdgcn_rcp(det);                            // v_rcp_f64 + two Newton steps
-    inv = fma(fma(-det, inv, 1.0), inv, inv);
-    inv = fma(fma(-det, inv, 1.0), inv, inv);
+    double axx, ayy, c, inv;
+    if (DC == 2) {
+        axx = dg->axx; ayy = dg->ayy; c = dg->c; inv = dg->inv;
+    } else {
+        const double Dxx = fma(-2.0, P, im[7] + im[1]);                   // OF.py:702-703
+        const double Dyy = fma(-2.0, P, im[5] + im[3]);                   // OF.py:704-705
+        const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;        // OF.py:700-701
+        const double m4a = -4.0 * alpha;
+        axx = fma(P, fma(-2.0, P, Dxx), m4a); ayy = fma(P, fma(-2.0, P, Dyy), m4a); c = P * Dxy;
+        const double det = fma(axx, ayy, -(c * c));
+        inv = __builtin_amdgcn_rcp(det);                                   // v_rcp_f64 + two Newton steps
+        inv = fma(fma(-det, inv, 1.0), inv, inv);
+        inv = fma(fma(-det, inv, 1.0), inv, inv);
+        if (DC == 1) { dg->axx = axx; dg->ayy = ayy; dg->c = c; dg->inv = inv; }
+    }
     u = fma(r0, ayy, -(c * r1)) * inv;
     w = fma(axx, r1, -(c * r0)) * inv;
     gm = fma(-Dy, w, fma(-Dx, u, r2)) * inv_g;
@@ -3004,15 +3014,13 @@ template <int NS, int TRAIL = 0> struct S0M {
 
 // Full operator product (A x)(p, q) of level 0 at one point from the 3x3 neighbourhoods of the image and of x (ghosts folded
 // by the caller, corner factors applied here), in the style of gs0_point.
-template <bool CORNERS>
+template <bool CORNERS, int DC = 0>
 __device__ __forceinline__ void apply0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
-                                             double alpha, double beta, int quirks, double& y0, double& y1, double& y2) {
+                                             double alpha, double beta, int quirks, double& y0, double& y1, double& y2,
+                                             const Diag0* dg = nullptr) {
     const double P = im[4];
     const double Dx = (im[7] - im[1]) * 0.5;
     const double Dy = quirks ? Dx : (im[5] - im[3]) * 0.5;
-    const double Dxx = fma(-2.0, P, im[7] + im[1]);
-    const double Dyy = fma(-2.0, P, im[5] + im[3]);
-    const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;
     const double PP = P * P, PDx = P * Dx, PDy = P * Dy, hP = 0.5 * P;
     const double A1 = PP + alpha, qPP = 0.25 * PP, hPDx = 0.5 * PDx, hPDy = 0.5 * PDy;
     const double du71 = n.u[7] - n.u[1], du53 = n.u[5] - n.u[3], dw71 = n.w[7] - n.w[1], dw53 = n.w[5] - n.w[3];
@@ -3024,8 +3032,16 @@ __device__ __forceinline__ void apply0_point(const double* im, const Nbr& n, dou
         W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
         U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
     }
-    const double m4a = -4.0 * alpha;
-    const double axx = fma(P, fma(-2.0, P, Dxx), m4a), ayy = fma(P, fma(-2.0, P, Dyy), m4a), c = P * Dxy;
+    double axx, ayy, c;
+    if (DC == 2) {   // diagonal block handed on by the sweep stages (gs0_point: the same expressions)
+        axx = dg->axx; ayy = dg->ayy; c = dg->c;
+    } else {
+        const double Dxx = fma(-2.0, P, im[7] + im[1]);
+        const double Dyy = fma(-2.0, P, im[5] + im[3]);
+        const double Dxy = (im[8] - im[6] - im[2] + im[0]) * 0.25;
+        const double m4a = -4.0 * alpha;
+        axx = fma(P, fma(-2.0, P, Dxx), m4a); ayy = fma(P, fma(-2.0, P, Dyy), m4a); c = P * Dxy;
+    }
     y0 = fma(hPDx, dw53, fma(alpha, n.u[3] + n.u[5], A1 * (n.u[1] + n.u[7]))) +
          fma(hP, n.g[1] - n.g[7], fma(qPP, W4, fma(hPDy, dw71, PDx * du71))) + fma(axx, n.u[4], c * n.w[4]);
     y1 = fma(hPDy, du71, fma(alpha, n.w[1] + n.w[7], A1 * (n.w[3] + n.w[5]))) +

@@ -45,6 +45,9 @@ __device__ __forceinline__ double lane_shl1(double v) {
     return __hiloint2double(hi, lo);
 }
 
+#ifndef VOF_S0R_DCACHE
+#define VOF_S0R_DCACHE 1
+#endif
 template <int NS, int TRAIL = 0> struct S0R {
     static constexpr int EXT = TRAIL ? 1 : 0;
     static constexpr int LO = 2 * NS + EXT;          // lowest live row of step e: e - LO (TRAIL: the row above the last final one)
@@ -53,7 +56,13 @@ template <int NS, int TRAIL = 0> struct S0R {
     static constexpr int IPW = 66;                   // doubles per parity half of an image row (65 used: full columns 0 .. 129)
     static constexpr int IRB = 2 * IPW * 8;          // bytes per image ring row
     static constexpr int NRI = LO + 2;               // image ring rows: e - LO .. e + 1; rows e + 2, e + 3 replace the two oldest
-    static constexpr int LDS_BYTES = NRI * IRB;
+    static constexpr int LDS_BYTES = NRI * IRB;      // the image ring (all k_sweep0p uses)
+    // the diagonal blocks of the first sweep's rows, handed on to the second sweep (and the trailing product) through LDS: rows
+    // e - 2 NS + 1 - EXT .. e, an even number of slots (the ring turns by two rows per step); a row = 4 values x 64 lanes x 16 B
+    static constexpr bool DC = (VOF_S0R_DCACHE != 0) && NS == 2;
+    static constexpr int ND = DC ? 2 * NS + 2 * EXT : 0;
+    static constexpr int DRB = 4 * 64 * 16;
+    static constexpr int LDS_TOTAL = LDS_BYTES + ND * DRB;
 };
 
 struct S0RRow { double2 u, w, g; };   // one x row of the strip: .x = column 2 lane, .y = column 2 lane + 1
@@ -71,8 +80,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
     typedef S0R<NS, TRAIL> G;
     constexpr int W = S0_W, LO = G::LO, NRW = G::NRW, NRI = G::NRI, IRB = G::IRB, IHB = G::IPW * 8, EXT = G::EXT;
     constexpr int NST = 2 * NS, po = PO;                                  // stages per step: E_0, O_0, E_1, O_1, ...: stage st works on row e - st
+    constexpr bool DC = G::DC;
+    constexpr int ND = G::ND, DRB = G::DRB;
     extern __shared__ double sw_lds[];
     char* iring = reinterpret_cast<char*>(sw_lds);
+    char* dring = iring + G::LDS_BYTES;
     const unsigned nblocks = (unsigned)nx * ny * nz;
     unsigned lb = blockIdx.x;
     if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
@@ -151,6 +163,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
 
     int islot = 0;                                                          // image ring slot of row e - LO
     auto irow = [&](int j) { int s = islot + j; if (s >= NRI) s -= NRI; return iring + s * IRB; };   // ring row of window row j (j < NRI)
+    int dslot = 0;                                                          // diagonal-block ring slot of row e
+    auto drow = [&](int k) { int s = dslot - k; if (s < 0) s += ND; return dring + s * DRB + lane * 16; };   // ... of row e - k
 
     // ---- requests: rows e + 2, e + 3 of x and of the image, the coarse row they need next
     auto request_rows = [&](auto edge_tag, int e) {
@@ -231,6 +245,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         const double iuA = LD(iu, ie), iuB = LD(iu, io), iuC = LD(iu, ie + 8), iuD = LD(iu, io + 8);
         const double icA = LD(ic, ie), icB = LD(ic, io), icC = LD(ic, ie + 8), icD = LD(ic, io + 8);
         const double idA = LD(id, ie), idB = LD(id, io), idC = LD(id, ie + 8), idD = LD(id, io + 8);
+        // diagonal blocks of the row's two points: the first sweep's stages store them, the later ones take them over
+        constexpr int stg_dc = LO - jc;                                     // stage number
+        constexpr int DCM = !DC ? 0 : (stg_dc < 2 ? 1 : 2);
+        double2 dq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};                   // axx, ayy, c, inv; .x / .y = even / odd column
+        if constexpr (DCM == 2) {
+            const char* dr = drow(stg_dc);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dq[v] = *reinterpret_cast<const double2*>(dr + v * 1024);
+        }
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             constexpr int par_of_ph[2] = {po, 1 - po};
@@ -284,14 +307,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             }
             const double c0 = par ? bs0.y : bs0.x, c1 = par ? bs1.y : bs1.x, c2 = par ? bs2.y : bs2.x;
             double u, w, gm;
+            Diag0 dg;
+            if (DCM == 2) {
+                if (par == 0) { dg.axx = dq[0].x; dg.ayy = dq[1].x; dg.c = dq[2].x; dg.inv = dq[3].x; }
+                else { dg.axx = dq[0].y; dg.ayy = dq[1].y; dg.c = dq[2].y; dg.inv = dq[3].y; }
+            }
             auto update = [&](auto zero_tag) {
                 constexpr int Z = decltype(zero_tag)::value;
                 if (EDGE) {
                     const double sUL = (oU && gl) ? 2.0 : 1.0, sUR = (oU && gr) ? 2.0 : 1.0;
                     const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
-                    gs0_point<true, Z>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
+                    gs0_point<true, Z, DCM>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm, &dg);
                 } else {
-                    gs0_point<false, Z>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm);
+                    gs0_point<false, Z, DCM>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm, &dg);
                 }
             };
             if (ZM == 1) update(std::integral_constant<int, 1>{});
@@ -300,6 +328,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             else update(std::integral_constant<int, 0>{});
             if (par == 0) { RC.u.x = u; RC.w.x = w; RC.g.x = gm; }
             else { RC.u.y = u; RC.w.y = w; RC.g.y = gm; }
+            if (DCM == 1) {
+                if (par == 0) { dq[0].x = dg.axx; dq[1].x = dg.ayy; dq[2].x = dg.c; dq[3].x = dg.inv; }
+                else { dq[0].y = dg.axx; dq[1].y = dg.ayy; dq[2].y = dg.c; dq[3].y = dg.inv; }
+            }
+        }
+        if constexpr (DCM == 1) {
+            char* dw = drow(stg_dc);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<double2*>(dw + v * 1024) = dq[v];
         }
     };
 
@@ -340,6 +377,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         const double iuA = LD(iu, ie), iuB = LD(iu, io), iuC = LD(iu, ie + 8), iuD = LD(iu, io + 8);
         const double icA = LD(ic, ie), icB = LD(ic, io), icC = LD(ic, ie + 8), icD = LD(ic, io + 8);
         const double idA = LD(id, ie), idB = LD(id, io), idC = LD(id, ie + 8), idD = LD(id, io + 8);
+        constexpr int DCT = DC ? 2 : 0;
+        double2 dq[3] = {{0, 0}, {0, 0}, {0, 0}};                           // axx, ayy, c of the row (stored by the first sweep's stage)
+        if constexpr (DC) {
+            const char* dr = drow(LO - jc);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) dq[v] = *reinterpret_cast<const double2*>(dr + v * 1024);
+        }
         double2 y[3];
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
@@ -378,12 +422,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
                 imv[0] = iuB; imv[1] = iuC; imv[2] = iuD; imv[3] = icB; imv[4] = icC; imv[5] = icD; imv[6] = idB; imv[7] = idC; imv[8] = idD;
             }
             double y0, y1, y2;
+            Diag0 dg;
+            if (par == 0) { dg.axx = dq[0].x; dg.ayy = dq[1].x; dg.c = dq[2].x; }
+            else { dg.axx = dq[0].y; dg.ayy = dq[1].y; dg.c = dq[2].y; }
+            dg.inv = 0.0;
             if (EDGE) {
                 const double sUL = (oU && gl) ? 2.0 : 1.0, sUR = (oU && gr) ? 2.0 : 1.0;
                 const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
-                apply0_point<true>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, quirks, y0, y1, y2);
+                apply0_point<true, DCT>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, quirks, y0, y1, y2, &dg);
             } else {
-                apply0_point<false>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, quirks, y0, y1, y2);
+                apply0_point<false, DCT>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, quirks, y0, y1, y2, &dg);
             }
             if (par == 0) { y[0].x = y0; y[1].x = y1; y[2].x = y2; }
             else { y[0].y = y0; y[1].y = y1; y[2].y = y2; }
@@ -455,6 +503,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             }
             islot += 2;
             if (islot >= NRI) islot -= NRI;
+            if (DC) { dslot += 2; if (dslot >= ND) dslot -= ND; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS operations of a wave execute in order; keeps the compiler from
             __builtin_amdgcn_wave_barrier();                         // moving next step's reads above these writes
         }
