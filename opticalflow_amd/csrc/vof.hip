@@ -149,6 +149,13 @@ struct vof_ctx {
     bool trail_enabled = true;  // VOF_FUSE_APPLY=0: always the separate operator kernel
     bool trail_set = false, trail_done = false;
     S0Trail trail_req;
+    // BiCGStab vector update folded into the cycle's first pre-smoothing pass (k_sweep0r, BF): set by the Krylov loop, consumed by
+    // the first level-0 pass from zero of the cycle (sweep_level_t), which resets bf_mode
+    bool s0r_bcarry = true;     // two-sweep pass from zero: b is read once and handed from the first sweep's stages to the second's in
+                                // registers (VOF_S0R_BCARRY=0: read once per sweep)
+    bool fuse_b = false;        // VOF_FUSE_B=1 (experiment, measured neutral: DESIGN.md 3.0): fold k_update_s / k_update_p into that pass
+    int bf_mode = 0;            // 0: none pending; 1: s = r - alpha v (+ (s, s), half-step test); 2: p = r + beta (p_old - omega v)
+    S0BSrc bf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int trail_nblk = 0;         // per-pair partial sums the fused pass wrote
     bool sweep0m = true;        // level 0, float64 vectors, even n_j: k_sweep0m (VOF_SWEEP0M=0: k_sweep0)
     bool sweep0m_pairs = true;  // ... two sweeps per pass (VOF_SWEEP0M=1: one sweep per pass)
@@ -590,6 +597,26 @@ inline bool sweep_st_usable(const vof_ctx* c, int l) {
     return l > 0 && c->L[l].C != nullptr && c->sweep_st && c->geo_b_stored && c->cfmt >= 2;
 }
 
+// Strips and bands of a level-0 pass of k_sweep0m / k_sweep0r (NSW sweeps per pass) and whether the register-resident kernel takes it
+struct S0Geo { int nx, ny, TI; bool s0r; };
+inline S0Geo s0_geometry(const vof_ctx* c, int rows, int NSW, bool trail) {
+    const Level& lv = c->L[0];
+    S0Geo g;
+    const int out = S0_W - 8 * NSW - (trail ? 4 : 0);
+    g.nx = (lv.nj + out - 1) / out;
+    g.TI = pick_band_height(rows, g.nx, c->cur_units);
+    g.ny = (rows + g.TI - 1) / g.TI;
+    g.s0r = c->sweep0r && c->prm.reference_quirks && c->pq_smooth && (long)g.nx * g.ny * std::max(1, c->cur_units) >= c->sweep0r_min_blocks;
+    return g;
+}
+
+// Will the next cycle start with a two-sweep level-0 pass from zero of k_sweep0r?  Then the vector update that forms the cycle's
+// right-hand side is folded into that pass (the conditions mirror vcycle_t -> smooth_level_t -> sweep_level_t).
+inline bool fold_b_usable(const vof_ctx* c) {
+    return c->fuse_b && !c->direct_on && !c->vfloat && c->L.size() > 1 && c->tail_first != 0 && c->fused && c->prm.nu_pre >= 2 &&
+           sweep0m_usable(c) && c->sweep0m_pairs && s0_geometry(c, c->L[0].ni, 2, false).s0r;
+}
+
 // One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
 // nsweeps = 2 (level 0, k_sweep0m only): two consecutive sweeps in one pass.
 template <typename VT>
@@ -607,14 +634,34 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             // k_sweep0m: merged colours, 16-byte accesses, `nsweeps` (1 or 2) sweeps per pass; strips are not shifted by po
             const int NSW = nsweeps >= 2 ? 2 : 1;
             const bool trail = with_trail && x_in != nullptr;
-            const int out = S0_W - 8 * NSW - (trail ? 4 : 0);
-            const int nx = (lv.nj + out - 1) / out;
-            const int TI = pick_band_height(rows, nx, c->cur_units);
-            const int ny = (rows + TI - 1) / TI;
+            const S0Geo geo = s0_geometry(c, rows, NSW, trail);
+            const int nx = geo.nx, TI = geo.TI, ny = geo.ny;
             dim3 g((unsigned)nx * ny * np, 1, 1);
             int nci = 0, ncj = 0;
             double ebytes = 0.0;
             if (ecoarse) { nci = c->L[1].ni; ncj = c->L[1].nj; ebytes = (ec32 ? 12.0 : 24.0) * c->L[1].npts; }
+            if (c->bf_mode) {   // the pass forms its right-hand side itself (the Krylov loop has checked fold_b_usable)
+                if (x_in || NSW != 2 || po || !geo.s0r || ecoarse || trail) { c->err = "folded vector update: the cycle did not start with the expected pass"; c->bf_mode = -1; return; }
+                const int mode = c->bf_mode;
+                c->bf_mode = 0;
+                Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, 1, c->pp};
+                S0Trail tr{nullptr, nullptr, 0, nullptr};
+                const size_t ldsr = S0R<2, 0>::LDS_TOTAL;
+                {   // I + r(3) + v(3) (+ p_old(3)) in, x(3) + b(3) out
+                    const double moved = (8.0 + (mode == 2 ? 15.0 : 12.0) * 8.0) * lv.npts;
+                    Prof p(c, VOF_K_GS0, 0, moved + 80.0 * lv.npts, moved);
+                    if (mode == 1) k_sweep0r<2, false, true, 0, double, 0, 1, 1><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 0, nx, ny, np, nullptr, x_out, b, active, nullptr, 0, 0, tr, 0, 0, c->bf);
+                    else k_sweep0r<2, false, true, 0, double, 0, 1, 2><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 0, nx, ny, np, nullptr, x_out, b, active, nullptr, 0, 0, tr, 0, 0, c->bf);
+                }
+                if (mode == 1) {   // (s, s): stopping rule at the half step; pairs done there get their x += alpha y and leave the cycle
+                    const size_t len = 3 * lv.npts;
+                    { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_S><<<np, 64, 0, c->stream>>>(c->sc, c->partials, nx * ny, c->active, c->prm.rtol, c->prm.max_iterations); }
+                    { Prof p(c, VOF_K_VECTOR, 0);
+                      k_fix_half<double><<<dim3(64, np), RBLK, 0, c->stream>>>(c->kx, (const double*)c->ky, len, c->sc);
+                      k_clear_half<<<(np + 255) / 256, 256, 0, c->stream>>>(c->sc, np); }
+                }
+                return;
+            }
             // bytes the pass moves: I + b(3) + x(3) in, x(3) out (+ coarse e), whatever the number of fused sweeps; algorithmic
             // bytes (80 per sweep performed): the second sweep of a double pass counts as a full sweep
             double moved = (8.0 + (x_in ? 9.0 : 6.0) * 8.0) * lv.npts + ebytes;
@@ -649,12 +696,13 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (trail && ecoarse) k_sweep0r<NS_, true, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (trail) k_sweep0r<NS_, false, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (ecoarse) k_sweep0r<NS_, true, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (!x_in && c->s0r_bcarry) k_sweep0r<NS_, false, true, 0, double, PO_, 1, ((NS_) == 2 && (PO_) == 0) ? 3 : 0><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0r<NS_, false, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
             // (the register-resident pass is compiled with the reference's derivative quirk built in; one wave per block needs
             // a few waves per SIMD-slot to fill the chip: tiny stacks - 128 x 128 x 8: 14 blocks - stay with the 4-wave LDS pass)
-            if (c->sweep0r && f0.quirks && (long)nx * ny * std::max(1, c->cur_units) >= c->sweep0r_min_blocks) {
+            if (geo.s0r) {
                 if (NSW == 2) { if (po) VOF_LAUNCH_S0R(2, 1); else VOF_LAUNCH_S0R(2, 0); }
                 else { if (po) VOF_LAUNCH_S0R(1, 1); else VOF_LAUNCH_S0R(1, 0); }
             }
@@ -1428,8 +1476,17 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         // p = r + beta (p - omega v).  The iteration after a (re)start has p = r: the cycle then runs straight on r (unless it
         // needs a float32 copy of its right-hand side) and no p is written - the next iteration finds that p in r^ = r0.
         const bool on_r = it == 0 && !c->vfloat;
+        const bool fold_b = fold_b_usable(c);
         if (on_r) vrhs_p = (void*)c->kr;
-        else {
+        else if (fold_b && it > 0) {
+            // folded into the cycle's first pass (k_sweep0r, BF = 2).  The new p goes to the buffer of t, which is dead here,
+            // and the two trade names (the bands of the pass overlap: no update in place)
+            const double* p_old = (it == 1 && ran_on_r) ? rh : c->kp;
+            c->bf = S0BSrc{c->kr, c->kv, p_old, c->kt, c->sc, nullptr};
+            c->bf_mode = 2;
+            std::swap(c->kp, c->kt);
+            vrhs_p = (void*)c->kp;
+        } else {
             Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * (it == 0 ? 2 : 4) + (c->vfloat ? 4.0 * len : 0.0));
             const double* p_old = (it == 1 && ran_on_r) ? rh : c->kp;
             VDISPATCH(c, (k_update_p<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kp, p_old, c->kr, c->kv, len, c->sc, act,
@@ -1441,20 +1498,31 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
         c->trail_set = true; c->trail_done = false;
         vcycle(c, &c->ky, vrhs_p, np, act);
         c->trail_set = false;
+        if (c->bf_mode) { if (c->err.empty()) c->err = "folded vector update (p): not consumed by the cycle"; c->bf_mode = 0; return -1; }
         int nb1 = c->trail_done ? c->trail_nblk : krylov_apply(c, c->ky, c->kv, np, act, rh, 0);
         if (!nb1) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(rh, c->kv, nullptr, nullptr, len, c->partials, act); nb1 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_ALPHA><<<np, 64, 0, s>>>(c->sc, c->partials, nb1, c->active, P.rtol, P.max_iterations); }
+        if (fold_b) {
+            // s = r - alpha v, (s, s), the half-step test and its x += alpha y: in / right after the first pass of the cycle on s
+            // (k_sweep0r, BF = 1).  s goes to the buffer of t (dead until the end of this cycle); r's buffer becomes t's
+            c->bf = S0BSrc{c->kr, c->kv, nullptr, c->kt, c->sc, c->partials};
+            c->bf_mode = 1;
+            std::swap(c->kr, c->kt);
+            vrhs_s = (void*)c->kr;
+        } else {
         { Prof p(c, VOF_K_VECTOR, 0, 8.0 * len * 3 + (c->vfloat ? 4.0 * len : 0.0));   // s = r - alpha v, (s, s)
           VDISPATCH(c, (k_update_s<VT><<<rgrid(c, np), RBLK, 0, s>>>(c->kr, c->kv, len, c->sc, c->partials, act, c->vfloat ? (VT*)c->b32 : (VT*)nullptr))); }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_S><<<np, 64, 0, s>>>(c->sc, c->partials, c->nblk, c->active, P.rtol, P.max_iterations); }
         { Prof p(c, VOF_K_VECTOR, 0);                                  // pairs done at the half step: x += alpha y
           VDISPATCH(c, (k_fix_half<VT><<<dim3(64, np), RBLK, 0, s>>>(c->kx, (const VT*)c->ky, len, c->sc)));
           k_clear_half<<<(np + 255) / 256, 256, 0, s>>>(c->sc, np); }
+        }
         // z = M s and t = A z with (t, s) and (t, t)
         c->trail_req = S0Trail{c->kt, c->kr, 1, c->partials};
         c->trail_set = true; c->trail_done = false;
         vcycle(c, &c->kz, vrhs_s, np, act);
         c->trail_set = false;
+        if (c->bf_mode) { if (c->err.empty()) c->err = "folded vector update (s): not consumed by the cycle"; c->bf_mode = 0; return -1; }
         int nb2 = c->trail_done ? c->trail_nblk : krylov_apply(c, c->kz, c->kt, np, act, c->kr, 1);
         if (!nb2) { Prof p(c, VOF_K_REDUCE, 0, 16.0 * len); k_dot2<<<rgrid(c, np), RBLK, 0, s>>>(c->kt, c->kr, c->kt, c->kt, len, c->partials, act); nb2 = c->nblk; }
         { Prof p(c, VOF_K_VECTOR, 0); k_scalar<S_OMEGA><<<np, 64, 0, s>>>(c->sc, c->partials, nb2, c->active, P.rtol, P.max_iterations); }
@@ -1720,6 +1788,8 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_SWEEP0R")) c->sweep0r = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0P")) c->sweep0p = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0R_MIN_BLOCKS")) c->sweep0r_min_blocks = atol(e);
+    if (const char* e = getenv("VOF_FUSE_B")) c->fuse_b = e[0] != '0';
+    if (const char* e = getenv("VOF_S0R_BCARRY")) c->s0r_bcarry = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0M")) { c->sweep0m = e[0] != '0'; c->sweep0m_pairs = e[0] != '0' && e[0] != '1'; }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;

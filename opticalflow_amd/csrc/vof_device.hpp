@@ -1310,8 +1310,8 @@ __global__ __launch_bounds__(RBLK) void k_update_p(double* p, const double* p_ol
             double2 a = ldnt2(r2 + i);
             if (!first) {
                 const double2 pp = ldnt2(q2 + i), vv = ldnt2(v2 + i);
-                a.x = a.x + beta * (pp.x - omega * vv.x);
-                a.y = a.y + beta * (pp.y - omega * vv.y);
+                a.x = fma(beta, fma(-omega, vv.x, pp.x), a.x);   // (written out: the folded form in k_sweep0r performs the same operations)
+                a.y = fma(beta, fma(-omega, vv.y, pp.y), a.y);
             }
             stnt2(p2 + i, a);
             if (c2) { V2 t; t.x = (VT)a.x; t.y = (VT)a.y; stnt2(c2 + i, t); }
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(RBLK) void k_update_p(double* p, const double* p_ol
     }
     for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
         double t = r[off + i];
-        if (!first) t = t + beta * (p_old[off + i] - omega * v[off + i]);
+        if (!first) t = fma(beta, fma(-omega, v[off + i], p_old[off + i]), t);
         p[off + i] = t;
         if (pcopy) pcopy[off + i] = (VT)t;
     }
@@ -1344,15 +1344,15 @@ __global__ __launch_bounds__(RBLK) void k_update_s(double* __restrict__ r, const
         V2* c2 = scopy ? reinterpret_cast<V2*>(scopy + off) : nullptr;
         for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len / 2; i += (size_t)gridDim.x * RBLK) {
             double2 a = ldnt2(r2 + i), vv = ldnt2(v2 + i);
-            a.x -= alpha * vv.x;
-            a.y -= alpha * vv.y;
+            a.x = fma(-alpha, vv.x, a.x);
+            a.y = fma(-alpha, vv.y, a.y);
             stnt2(r2 + i, a);
             if (c2) { V2 t; t.x = (VT)a.x; t.y = (VT)a.y; stnt2(c2 + i, t); }
             ss += a.x * a.x + a.y * a.y;
         }
     } else {
         for (size_t i = (size_t)blockIdx.x * RBLK + threadIdx.x; i < len; i += (size_t)gridDim.x * RBLK) {
-            double s = r[off + i] - alpha * v[off + i];
+            double s = fma(-alpha, v[off + i], r[off + i]);
             r[off + i] = s;
             if (scopy) scopy[off + i] = (VT)s;
             ss += s * s;
@@ -3055,6 +3055,18 @@ struct S0Trail {           // trailing operator stage (TRAIL = 1): v = A x_out, 
     const double* dotvec; // or nullptr
     int want_vv;          // slot 0 = (v, dotvec) or, without dotvec, (v, v); slot 1 = (v, v) when both are asked for
     double* partials;     // [pair][3][nblk], nblk = nx * ny blocks per pair
+};
+
+// BiCGStab vector update folded into the first pre-smoothing pass of the cycle that consumes its result (k_sweep0r, BF):
+// mode 1: s = r - alpha v and the block partial sums of (s, s); mode 2: p = r + beta (p_old - omega v).  `out` is a buffer
+// of its own (the bands of the pass overlap: updating in place would feed a neighbouring band the new values).
+struct S0BSrc {
+    const double* r;
+    const double* v;
+    const double* p_old;          // mode 2
+    double* out;                  // [pair][3][npts]
+    const PairScalars* sc;        // alpha / beta, omega per pair
+    double* partials;             // mode 1: [pair][3][nblk], nblk = nx * ny blocks per pair
 };
 
 // ET: storage type of the coarse-grid correction (float when the levels below 0 keep their vectors in float32)

@@ -48,6 +48,9 @@ __device__ __forceinline__ double lane_shl1(double v) {
 #ifndef VOF_S0R_DCACHE
 #define VOF_S0R_DCACHE 1
 #endif
+#ifndef VOF_S0R_FZ_WAVES
+#define VOF_S0R_FZ_WAVES 2      // waves per SIMD of the pass from zero
+#endif
 template <int NS, int TRAIL = 0> struct S0R {
     static constexpr int EXT = TRAIL ? 1 : 0;
     static constexpr int LO = 2 * NS + EXT;          // lowest live row of step e: e - LO (TRAIL: the row above the last final one)
@@ -70,11 +73,17 @@ struct S0RRow { double2 u, w, g; };   // one x row of the strip: .x = column 2 l
 // PO: 0 = forward colour order 0, 1, 2, 3; 1 = reverse order (rows shifted by one, odd columns first) - a template parameter
 // so that the column parity of a phase is a compile-time constant (one code path per phase)
 // QK: the reference's 'dy' == 'dx' quirk (OF.py:698-699) as a compile-time constant (the select costs four instructions per point)
-template <int NS, bool EC, bool FROM_ZERO, int TRAIL, typename ET, int PO, int QK = 1>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 2 : 1, FROM_ZERO ? 2 : 1))) void k_sweep0r(
+// BF: the right-hand side of a pass from zero is FORMED here instead of read - the BiCGStab vector update that would have written
+// it is folded into the pass (S0BSrc): 1: s = r - alpha v (+ the block partial sums of (s, s)), 2: p = r + beta (p_old - omega v).
+// Stages 0 / 1 (first sweep) read the operand rows, form b, store the owned part and hand the row on to stages 2 / 3 (second
+// sweep, one step later) in registers, so b is neither written and re-read nor read twice.  One wave per SIMD (register budget).
+template <int NS, bool EC, bool FROM_ZERO, int TRAIL, typename ET, int PO, int QK = 1, int BF = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO && (BF == 0 || BF == 3)) ? VOF_S0R_FZ_WAVES : 1, (FROM_ZERO && (BF == 0 || BF == 3)) ? VOF_S0R_FZ_WAVES : 1))) void k_sweep0r(
     Fine0 pol, int ni, int nj, int TI, int /*po*/, int nx, int ny, int nz, const double* __restrict__ x_in,
     double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
-    const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr, int skip_first = 0, int skip_count = 0) {
+    const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr, int skip_first = 0, int skip_count = 0,
+    S0BSrc bsrc = S0BSrc{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
+    static_assert(BF == 0 || (FROM_ZERO && NS == 2 && !EC && TRAIL == 0 && PO == 0), "the folded vector update belongs to the first pre-smoothing pass");
     // (skip_first, skip_count: the strips [skip_first, skip_first + skip_count) belong to another launch - k_sweep0p takes the
     // interior strips in its mode -; nx counts the strips of THIS launch)
     typedef S0R<NS, TRAIL> G;
@@ -129,6 +138,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
 #pragma unroll
     for (int j = 0; j < NRW; ++j) X[j].u = X[j].w = X[j].g = double2{0.0, 0.0};
     double2 B[NST][3];                                                     // b of the stage's row (requested one step ahead)
+    double2 BV[2][3], BQ[2][3];                                            // BF: the v (and p_old) rows of stages 0, 1
+    double2 BC[2][2][3];                                                   // BF: b rows handed on: [this / next step's][stage 0 / 1][field]
+    double bss = 0.0, bcA = 0.0, bcB = 0.0;
+    const double* bfr = nullptr; const double* bfv = nullptr; const double* bfq = nullptr; double* bfo = nullptr;
+    if constexpr (BF == 3) bfr = bp;     // 3: b itself, read once (no update folded in) and handed on like the formed rows
+    if constexpr (BF != 0) {
+        if (BF != 3) { bfr = bsrc.r + off; bfv = bsrc.v + off; bfo = bsrc.out + off; }
+        if (BF == 1) bcA = bsrc.sc[pair].alpha;
+        if (BF == 2) { bfq = bsrc.p_old + off; bcA = bsrc.sc[pair].beta; bcB = bsrc.sc[pair].omega; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) { BV[a][f] = BQ[a][f] = BC[0][a][f] = BC[1][a][f] = double2{0.0, 0.0}; }
+    }
     double2 li[2] = {{0, 0}, {0, 0}}, lix[2] = {{0, 0}, {0, 0}};           // image rows e + 2, e + 3 in flight
     ET crv[3] = {0, 0, 0};                                                 // EC: the coarse row in flight
     double CR[2][3];                                                       // EC: coarse rows (cp0, cp0 + 1) of the rows entering the window
@@ -213,12 +236,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         constexpr int st = decltype(st_tag)::value;
         const int rr = e_next - st, p = p0 + rr;
         const bool rowok = EDGE ? (rr >= st_lo(st) && rr <= st_hi(st) && p >= 0 && p < ni) : true;
-        if (EDGE) B[st][0] = B[st][1] = B[st][2] = double2{0.0, 0.0};
-        if (EDGE ? (rowok && pair_ok) : true) {
-            const double* brow = bp + (size_t)p * nj + qg;
-            B[st][0] = *reinterpret_cast<const double2*>(brow);
-            B[st][1] = *reinterpret_cast<const double2*>(brow + npts);
-            B[st][2] = *reinterpret_cast<const double2*>(brow + 2 * npts);
+        if constexpr (BF != 0) {
+            if constexpr (st < 2) {   // operand rows of the folded update (stages 2, 3 get their b handed on)
+                if (EDGE) {
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) B[st][f] = BV[st][f] = BQ[st][f] = double2{0.0, 0.0};
+                }
+                if (EDGE ? (rowok && pair_ok) : true) {
+                    const size_t ro = (size_t)p * nj + qg;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        B[st][f] = *reinterpret_cast<const double2*>(bfr + ro + f * npts);
+                        if (BF != 3) BV[st][f] = *reinterpret_cast<const double2*>(bfv + ro + f * npts);
+                        if (BF == 2) BQ[st][f] = *reinterpret_cast<const double2*>(bfq + ro + f * npts);
+                    }
+                }
+            }
+        } else {
+            if (EDGE) B[st][0] = B[st][1] = B[st][2] = double2{0.0, 0.0};
+            if (EDGE ? (rowok && pair_ok) : true) {
+                const double* brow = bp + (size_t)p * nj + qg;
+                B[st][0] = *reinterpret_cast<const double2*>(brow);
+                B[st][1] = *reinterpret_cast<const double2*>(brow + npts);
+                B[st][2] = *reinterpret_cast<const double2*>(brow + 2 * npts);
+            }
         }
     };
 
@@ -459,7 +500,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
             constexpr int ST = decltype(st_tag)::value;
             const int rr = e - ST, p = p0 + rr;
             const bool rowok = EDGE ? (rr >= st_lo(ST) && rr <= st_hi(ST) && p >= 0 && p < ni) : true;
-            if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, B[ST]);
+            if constexpr (BF != 0 && ST < 2) {
+                // form the row of b (the operations of k_update_s / k_update_p), store the owned part, hand the row on
+                double2 bs[3];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    if (BF == 3) {
+                        bs[f] = B[ST][f];
+                    } else if (BF == 1) {
+                        bs[f].x = fma(-bcA, BV[ST][f].x, B[ST][f].x);
+                        bs[f].y = fma(-bcA, BV[ST][f].y, B[ST][f].y);
+                    } else {
+                        bs[f].x = fma(bcA, fma(-bcB, BV[ST][f].x, BQ[ST][f].x), B[ST][f].x);
+                        bs[f].y = fma(bcA, fma(-bcB, BV[ST][f].y, BQ[ST][f].y), B[ST][f].y);
+                    }
+                    BC[1][ST][f] = bs[f];
+                }
+                const bool own = st_ok && rr >= 0 && rr < TI && p < ni;    // (p >= 0: the bands of a forward pass start at row 0)
+                if (BF != 3 && own) {
+                    double* orow = bfo + (size_t)p * nj + qg;
+                    *reinterpret_cast<double2*>(orow) = bs[0];
+                    *reinterpret_cast<double2*>(orow + npts) = bs[1];
+                    *reinterpret_cast<double2*>(orow + 2 * npts) = bs[2];
+                }
+                if (BF == 1) {
+                    const double q = (bs[0].x * bs[0].x + bs[0].y * bs[0].y) + (bs[1].x * bs[1].x + bs[1].y * bs[1].y) + (bs[2].x * bs[2].x + bs[2].y * bs[2].y);
+                    bss += own ? q : 0.0;
+                }
+                if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, bs);
+            } else if constexpr (BF != 0) {
+                if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, BC[0][ST - 2]);
+            } else {
+                if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, B[ST]);
+            }
             request_b(edge_tag, st_tag, e + 2);
         };
         run_stage(std::integral_constant<int, 0>{});
@@ -555,6 +628,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         }
 #pragma unroll
         for (int j = 0; j + 2 < NRW; ++j) X[j] = X[j + 2];
+        if constexpr (BF != 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) BC[0][a][f] = BC[1][a][f];
+        }
     };
 
     // ---- prologue: b of the first step's stages; EC: the coarse rows the first entering rows need
@@ -582,6 +661,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FROM_ZERO ? 
         // per-phase branch at all and is one basic block per step)
         if (e >= e_lo && e <= e_hi && !border_strip) step(std::false_type{}, std::false_type{}, e);
         else step(std::true_type{}, std::true_type{}, e);
+    }
+    if constexpr (BF == 1) {      // per-block partial sums of (s, s), laid out like the trailing product's
+        const double a0 = wave_sum(bss);
+        if (lane == 0) bsrc.partials[((size_t)pair * 3) * ((size_t)nx * ny) + (size_t)by * nx + bx] = a0;
     }
     if constexpr (TRAIL != 0) {   // per-block partial sums of the dot products
         const double a0 = wave_sum(ts0), a1 = wave_sum(ts1);

@@ -477,3 +477,32 @@ def test_debug_switches_guard_regions_poison_and_batch_time(native, monkeypatch)
     st = got[4]
     assert st["converged"].all() and np.isfinite(st["relative_residual"]).all()
     assert (st["batch_pairs"] == 3).all() and (st["batch_ms"] > 0).all() and np.ptp(st["batch_ms"]) == 0
+
+
+@pytest.mark.gpu
+def test_vector_updates_folded_into_the_first_pass_of_the_cycle(native, monkeypatch):
+    """VOF_FUSE_B=1 (include/vof.h): the BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) are formed inside the
+    first pre-smoothing pass of the cycle that consumes them (k_sweep0r, BF = 1 / 2) by the operations of k_update_s /
+    k_update_p.  Same iteration counts, the same solution up to the summation order of (s, s), fewer launches of the vector
+    class; the default (b read once and handed on in registers, BF = 3) against VOF_S0R_BCARRY=0 is bit-identical."""
+    mv = make_case("texture", (200, 264), 4, 5)
+    p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9)
+
+    def run():
+        with native.Solver(200, 264, 4) as s:
+            s.profile_enable(True)
+            out = s.solve_host(mv, p)
+            return out, s.profile_get("vector", 0)[0], s.profile_get("gs0", 0)[0]
+
+    ref, nvec_ref, ngs_ref = run()
+    monkeypatch.setenv("VOF_S0R_BCARRY", "0")
+    twice, _, _ = run()
+    for a, b in zip(twice[:4], ref[:4]):
+        np.testing.assert_array_equal(a, b)
+    monkeypatch.delenv("VOF_S0R_BCARRY")
+    monkeypatch.setenv("VOF_FUSE_B", "1")
+    got, nvec, ngs = run()
+    assert ngs == ngs_ref and nvec < nvec_ref - 2
+    assert (got[4]["iterations"] == ref[4]["iterations"]).all() and got[4]["converged"].all()
+    for a, b in zip(got[:4], ref[:4]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
