@@ -127,8 +127,6 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *                              (default: k_sweep0m, two sweeps per pass)
  *   VOF_SWEEP0R=0              level 0, float64 vectors: the LDS-ring pass k_sweep0m instead of the register-resident k_sweep0r
  *   VOF_SWEEP0R_MIN_BLOCKS=n   ... k_sweep0r from n one-wave blocks per launch on (default 512; smaller launches use k_sweep0m)
- *   VOF_S0R_BCARRY=0           ... the two-sweep pass from zero reads b once per sweep instead of handing it from the first sweep's
- *                              stages to the second's in registers
  *   VOF_FUSE_B=1               experiment: the BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) are formed inside the
  *                              first pre-smoothing pass of the cycle that consumes them (same bits; measured neutral, default off)
  *   VOF_SWEEP0P=0              level 0, float32 vectors: k_sweep0 (float64 arithmetic) instead of the packed-float32 k_sweep0p

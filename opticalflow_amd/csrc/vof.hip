@@ -151,8 +151,11 @@ struct vof_ctx {
     S0Trail trail_req;
     // BiCGStab vector update folded into the cycle's first pre-smoothing pass (k_sweep0r, BF): set by the Krylov loop, consumed by
     // the first level-0 pass from zero of the cycle (sweep_level_t), which resets bf_mode
-    bool s0r_bcarry = true;     // two-sweep pass from zero: b is read once and handed from the first sweep's stages to the second's in
-                                // registers (VOF_S0R_BCARRY=0: read once per sweep)
+    // residual + restriction of level 0 as the trailing stage of the pre-smoothing pass (k_sweep0r, TRAIL = 2): requested by
+    // vcycle_t around the pre-smoothing of level 0, honoured by sweep_level_t when the pass is the two-sweep pass from zero
+    bool fuse_rr = true;        // VOF_FUSE_RR=0: the stand-alone kernel k_stream_resrestrict0
+    void* rr_out = nullptr;     // coarse right-hand side to write (nullptr: not requested)
+    bool rr_f32 = false, rr_done = false;
     bool fuse_b = false;        // VOF_FUSE_B=1 (experiment, measured neutral: DESIGN.md 3.0): fold k_update_s / k_update_p into that pass
     int bf_mode = 0;            // 0: none pending; 1: s = r - alpha v (+ (s, s), half-step test); 2: p = r + beta (p_old - omega v)
     S0BSrc bf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -634,7 +637,10 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             // k_sweep0m: merged colours, 16-byte accesses, `nsweeps` (1 or 2) sweeps per pass; strips are not shifted by po
             const int NSW = nsweeps >= 2 ? 2 : 1;
             const bool trail = with_trail && x_in != nullptr;
-            const S0Geo geo = s0_geometry(c, rows, NSW, trail);
+            // the coarse right-hand side R (b - A x_out) as the trailing stage of the two-sweep pass from zero (k_sweep0r only)
+            const bool rr = c->rr_out && !x_in && NSW == 2 && !po && !ecoarse && !c->bf_mode && VOF_S0R_BCARRY &&
+                            s0_geometry(c, rows, NSW, true).s0r;
+            const S0Geo geo = s0_geometry(c, rows, NSW, trail || rr);
             const int nx = geo.nx, TI = geo.TI, ny = geo.ny;
             dim3 g((unsigned)nx * ny * np, 1, 1);
             int nci = 0, ncj = 0;
@@ -675,6 +681,12 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 c->trail_nblk = nx * ny;
                 c->trail_done = true;
             }
+            if (rr) {   // + the coarse right-hand side out (x_out, b and the image are in registers / LDS); algorithmic: the 56 B per
+                        // pixel the stand-alone residual + restriction kernel reads
+                const double cb = (c->rr_f32 ? 12.0 : 24.0) * c->L[1].npts;
+                algo += 56.0 * lv.npts + cb;
+                moved += cb;
+            }
             Prof p(c, VOF_K_GS0, 0, algo, moved);
             Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, c->prm.reference_quirks && c->pq_smooth, c->pp};
             const size_t lds = (size_t)(6 * NSW + 2 + (trail ? 4 : 0)) * s0_row_bytes(8) + (ecoarse ? (size_t)9 * (S0_W / 2 + 2) * 8 : 0);
@@ -688,6 +700,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (!x_in) k_sweep0m<NS_, false, true, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0m<NS_, false, false, 0><<<g, 128 * NS_, lds, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
+#define S0R_BF(NS_) ((VOF_S0R_BCARRY && (NS_) == 2) ? 3 : 0)   /* the two-sweep pass from zero reads b once (vof_sweep0r.hpp) */
 #define VOF_LAUNCH_S0R(NS_, PO_)                                                                                                   \
             do {                                                                                                                    \
                 const size_t ldsr = trail ? S0R<NS_, 1>::LDS_TOTAL : S0R<NS_, 0>::LDS_TOTAL;                                         \
@@ -696,18 +709,26 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 else if (trail && ecoarse) k_sweep0r<NS_, true, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (trail) k_sweep0r<NS_, false, false, 1, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else if (ecoarse) k_sweep0r<NS_, true, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
-                else if (!x_in && c->s0r_bcarry) k_sweep0r<NS_, false, true, 0, double, PO_, 1, ((NS_) == 2 && (PO_) == 0) ? 3 : 0><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
-                else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
+                else if (!x_in) k_sweep0r<NS_, false, true, 0, double, PO_, 1, S0R_BF(NS_)><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
                 else k_sweep0r<NS_, false, false, 0, double, PO_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, ecoarse, nci, ncj, tr); \
             } while (0)
             // (the register-resident pass is compiled with the reference's derivative quirk built in; one wave per block needs
             // a few waves per SIMD-slot to fill the chip: tiny stacks - 128 x 128 x 8: 14 blocks - stay with the 4-wave LDS pass)
+            if (rr) {
+                S0Trail trr{(double*)c->rr_out, nullptr, 0, nullptr};
+                const size_t ldsr = S0R<2, 2>::LDS_TOTAL;
+                if (c->rr_f32) k_sweep0r<2, false, true, 2, float, 0, 1, 3><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, nullptr, c->L[1].ni, c->L[1].nj, trr);
+                else k_sweep0r<2, false, true, 2, double, 0, 1, 3><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, po, nx, ny, np, x_in, x_out, b, active, nullptr, c->L[1].ni, c->L[1].nj, trr);
+                c->rr_done = true;
+                return;
+            }
             if (geo.s0r) {
                 if (NSW == 2) { if (po) VOF_LAUNCH_S0R(2, 1); else VOF_LAUNCH_S0R(2, 0); }
                 else { if (po) VOF_LAUNCH_S0R(1, 1); else VOF_LAUNCH_S0R(1, 0); }
             }
             else if (NSW == 2) VOF_LAUNCH_S0M(2); else VOF_LAUNCH_S0M(1);
 #undef VOF_LAUNCH_S0R
+#undef S0R_BF
 #undef VOF_LAUNCH_S0M
             return;
         }
@@ -918,6 +939,14 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
     // the ping-pong partner (the caller only reads the buffer this function returns), so the two just trade names - and the
     // partner then still holds the input of the last sweep, which is all k_resrestrict_u needs besides the result.
     const bool resu = l > 0 && lv.C != nullptr && c->fused && c->fuse_resu && nu1 >= 1;
+    bool rr_fused = false;   // level 0: the coarse right-hand side came out of the pre-smoothing pass (k_sweep0r, TRAIL = 2)
+    if constexpr (std::is_same<VT, double>::value) {
+        if (l == 0 && c->fuse_rr && from_zero && nu1 == 2 && lv.C == nullptr && c->stream_apply && c->fuse_restrict && sweep0m_usable(c) && c->sweep0m_pairs) {
+            c->rr_f32 = coarse32_ok(c, nu2);
+            c->rr_out = nx.b;
+            c->rr_done = false;
+        }
+    }
     if (l > 0 && c->fused) {
         VT* xr = smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active, nullptr, /*allow_swap=*/true, false, false, false,
                                     /*skip0=*/after_post && !from_zero && nu2 >= 1 && c->skip_colour0);
@@ -925,11 +954,12 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
     } else {
         smooth_level_t<VT>(c, l, x, tmp, b, nu1, from_zero, false, np, active);
     }
+    if (l == 0 && c->rr_out) { rr_fused = c->rr_done; c->rr_out = nullptr; c->rr_done = false; }
     if constexpr (std::is_same<VT, double>::value) {
         if (l == 0 && coarse32_ok(c, nu2)) {
             // float64 vectors on level 0, float32 below: the fused residual + restriction writes the coarse right-hand side as
             // float32, the levels below run in float32, and the post-smoothing pass interpolates the float32 correction
-            resrestrict_fine_t<double, float>(c, x, b, (float*)nx.b, np, active);
+            if (!rr_fused) resrestrict_fine_t<double, float>(c, x, b, (float*)nx.b, np, active);
             float* fx = (float*)nx.x;
             float* ft = (float*)nx.x2;
             // The last visit of level 1 hands its result up as float64 when its last operation is a k_sweep_st sweep (a regular
@@ -956,7 +986,7 @@ VT* vcycle_t(vof_ctx* c, int l, VT* x, VT* tmp, const VT* b, int np, const int* 
         const VT* x_old = (from_zero && nu1 == 1) ? nullptr : tmp;
         resrestrict_u_t<VT>(c, l, x, x_old, (VT*)nx.b, np, active);
     } else if (l == 0 && lv.C == nullptr && c->stream_apply && c->fuse_restrict) {
-        resrestrict_fine_t<VT>(c, x, b, (VT*)nx.b, np, active);
+        if (!rr_fused) resrestrict_fine_t<VT>(c, x, b, (VT*)nx.b, np, active);
     } else {
         apply_level_t<VT>(c, l, x, b, (VT*)lv.r, 1, np, active);
         restrict_level_t<VT>(c, l, (const VT*)lv.r, (VT*)nx.b, np, active);
@@ -1789,7 +1819,7 @@ static int create_impl(vof_ctx* c, int device_id, int n_i, int n_j, int B, void*
     if (const char* e = getenv("VOF_SWEEP0P")) c->sweep0p = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0R_MIN_BLOCKS")) c->sweep0r_min_blocks = atol(e);
     if (const char* e = getenv("VOF_FUSE_B")) c->fuse_b = e[0] != '0';
-    if (const char* e = getenv("VOF_S0R_BCARRY")) c->s0r_bcarry = e[0] != '0';
+    if (const char* e = getenv("VOF_FUSE_RR")) c->fuse_rr = e[0] != '0';
     if (const char* e = getenv("VOF_SWEEP0M")) { c->sweep0m = e[0] != '0'; c->sweep0m_pairs = e[0] != '0' && e[0] != '1'; }
     // level shapes
     Level l0; l0.ni = n_i - 2; l0.nj = n_j - 2; l0.npts = (size_t)l0.ni * l0.nj;

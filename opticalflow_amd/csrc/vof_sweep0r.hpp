@@ -48,6 +48,10 @@ __device__ __forceinline__ double lane_shl1(double v) {
 #ifndef VOF_S0R_DCACHE
 #define VOF_S0R_DCACHE 1
 #endif
+#ifndef VOF_S0R_BCARRY
+#define VOF_S0R_BCARRY 1        // two-sweep pass from zero: b is read once and handed on in registers (BF = 3); 0: read once per sweep
+                                // (the passes with one wave per SIMD lose 5 % with it - measured -, so only that one)
+#endif
 #ifndef VOF_S0R_FZ_WAVES
 #define VOF_S0R_FZ_WAVES 2      // waves per SIMD of the pass from zero
 #endif
@@ -78,12 +82,18 @@ struct S0RRow { double2 u, w, g; };   // one x row of the strip: .x = column 2 l
 // Stages 0 / 1 (first sweep) read the operand rows, form b, store the owned part and hand the row on to stages 2 / 3 (second
 // sweep, one step later) in registers, so b is neither written and re-read nor read twice.  One wave per SIMD (register budget).
 template <int NS, bool EC, bool FROM_ZERO, int TRAIL, typename ET, int PO, int QK = 1, int BF = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO && (BF == 0 || BF == 3)) ? VOF_S0R_FZ_WAVES : 1, (FROM_ZERO && (BF == 0 || BF == 3)) ? VOF_S0R_FZ_WAVES : 1))) void k_sweep0r(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO && (BF == 0 || BF == 3) && TRAIL != 2) ? VOF_S0R_FZ_WAVES : 1, (FROM_ZERO && (BF == 0 || BF == 3) && TRAIL != 2) ? VOF_S0R_FZ_WAVES : 1))) void k_sweep0r(
     Fine0 pol, int ni, int nj, int TI, int /*po*/, int nx, int ny, int nz, const double* __restrict__ x_in,
     double* __restrict__ x_out, const double* __restrict__ b, const int* __restrict__ active,
     const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr, int skip_first = 0, int skip_count = 0,
     S0BSrc bsrc = S0BSrc{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
-    static_assert(BF == 0 || (FROM_ZERO && NS == 2 && !EC && TRAIL == 0 && PO == 0), "the folded vector update belongs to the first pre-smoothing pass");
+    static_assert(BF == 0 || NS == 2, "b is handed from the first sweep's stages to the second's");
+    static_assert(BF == 0 || BF == 3 || (FROM_ZERO && !EC && TRAIL == 0 && PO == 0), "the folded vector update belongs to the first pre-smoothing pass");
+    // TRAIL = 2: the trailing stage forms the RESIDUAL b - A x_out of the rows that have just become final and restricts it (full
+    // weighting, R = P^T / 4, as k_stream_resrestrict0) - the coarse right-hand side comes out of the pre-smoothing pass and the
+    // residual + restriction kernel's pass over x, b and the image is gone.  ET = type of the coarse right-hand side, written to tr.v.
+    static_assert(TRAIL != 2 || (FROM_ZERO && !EC && PO == 0 && BF == 3), "the residual + restriction stage belongs to the pre-smoothing pass");
+    constexpr bool RR = TRAIL == 2;
     // (skip_first, skip_count: the strips [skip_first, skip_first + skip_count) belong to another launch - k_sweep0p takes the
     // interior strips in its mode -; nx counts the strips of THIS launch)
     typedef S0R<NS, TRAIL> G;
@@ -156,11 +166,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
     ET crv[3] = {0, 0, 0};                                                 // EC: the coarse row in flight
     double CR[2][3];                                                       // EC: coarse rows (cp0, cp0 + 1) of the rows entering the window
     double2 tn[2][3];                                                      // TRAIL: dot partner of the next step's two rows
+    double2 BCo[3];                                                        // RR: b of row e - 4 (stage 2's of the previous step)
+    double hprev[3] = {0.0, 0.0, 0.0};                                     // RR: column-restricted residual of row e - 5
     double ts0 = 0.0, ts1 = 0.0;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int f = 0; f < 3; ++f) { CR[r][f] = 0.0; tn[r][f] = double2{0.0, 0.0}; }
+        for (int f = 0; f < 3; ++f) { CR[r][f] = 0.0; tn[r][f] = double2{0.0, 0.0}; BCo[f] = double2{0.0, 0.0}; }
 
     // row ranges of the stages (as k_sweep0m): E_k rows [-2 m, TI + 2 m], O_k rows [-2 m + 1, TI + 2 m - 1], m = NS - 1 - k + EXT
     auto st_lo = [](int st) { const int k = st >> 1, odd = st & 1; return -2 * (NS - 1 - k + EXT) + odd; };
@@ -382,14 +394,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
     };
 
     // ---- trailing operator stage on window row jc (final, and so are its neighbours): v = A x_out + the dot products
-    auto trail_row = [&](auto edge_tag, auto border_tag, auto jc_tag, int rr, auto slot_tag) {
+    auto trail_row = [&](auto edge_tag, auto border_tag, auto jc_tag, int rr, auto slot_tag, double2 (&yout)[3]) -> bool {
         constexpr bool EDGE = decltype(edge_tag)::value;
         constexpr bool BORDER = decltype(border_tag)::value;
         constexpr int jc = decltype(jc_tag)::value < 1 ? 1 : decltype(jc_tag)::value;   // (never instantiated below 1 when TRAIL is set)
         constexpr int slot = decltype(slot_tag)::value;
         const int p = p0 + rr;
         const double2 t0 = tn[slot][0], t1 = tn[slot][1], t2 = tn[slot][2];
-        {   // the dot partner of the NEXT step's row
+        if constexpr (!RR) {   // the dot partner of the NEXT step's row
             const bool nrow = EDGE ? (rr + 2 >= 0 && rr + 2 < TI && p + 2 >= 0 && p + 2 < ni) : true;
             if (EDGE) tn[slot][0] = tn[slot][1] = tn[slot][2] = double2{0.0, 0.0};
             // (no dot partner given: the loads read v itself - valid memory, values unused - so that the steady state has no branch)
@@ -401,8 +413,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                 tn[slot][2] = *reinterpret_cast<const double2*>(drow + 2 * npts);
             }
         }
-        const bool rowok = EDGE ? (rr >= 0 && rr < TI && p >= 0 && p < ni) : true;
-        if (!rowok) return;
+        const bool rowok = EDGE ? (rr >= (RR ? -1 : 0) && rr < TI && p >= 0 && p < ni) : true;   // (RR: the coarse row of fine row 0 takes row -1 in)
+        if (!rowok) return false;
         const bool oU = EDGE && p - 1 < 0, oD = EDGE && p + 1 >= ni;
         S0RRow RU = X[jc - 1], RD = X[jc + 1];
         const S0RRow RC = X[jc];
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
             if (par == 0) { y[0].x = y0; y[1].x = y1; y[2].x = y2; }
             else { y[0].y = y0; y[1].y = y1; y[2].y = y2; }
         }
+        if constexpr (RR) { yout[0] = y[0]; yout[1] = y[1]; yout[2] = y[2]; return true; }
         // (only the three stores sit under the lane predicate: a short predicated region gets no skip branch, so the steady-state
         // step stays one basic block; the sums of the lanes outside the owned columns are masked with a select)
         if (st_ok) {
@@ -489,6 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
         const double vt = (y[0].x * t0.x + y[1].x * t1.x + y[2].x * t2.x) + (y[0].y * t0.y + y[1].y * t1.y + y[2].y * t2.y);
         ts0 += st_ok ? (tr.dotvec ? vt : vv) : 0.0;
         ts1 += st_ok ? vv : 0.0;
+        return true;
     };
 
     auto step = [&](auto edge_tag, auto border_tag, const int e) {
@@ -542,9 +556,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
             run_stage(std::integral_constant<int, 3>{});
         }
         // ---- (3) trailing stage on the rows that have just become final: e - 2 NS + 1 and e - 2 NS
-        if constexpr (TRAIL != 0) {
-            trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS + 1>{}, e - 2 * NS + 1, std::integral_constant<int, 1>{});
-            trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS>{}, e - 2 * NS, std::integral_constant<int, 0>{});
+        if constexpr (TRAIL == 1) {
+            double2 yd[3];
+            trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS + 1>{}, e - 2 * NS + 1, std::integral_constant<int, 1>{}, yd);
+            trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS>{}, e - 2 * NS, std::integral_constant<int, 0>{}, yd);
+        }
+        if constexpr (RR) {
+            // residual rows e - 4 (even fine row 2 cp) and e - 3 (2 cp + 1); b of the two rows: what stage 2 used in the previous step
+            // and what stage 3 used in this one.  Lanes without a column pair and rows outside the image contribute zero.
+            double2 ya[3], yb[3];
+            const bool okb = trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS + 1>{}, e - 2 * NS + 1, std::integral_constant<int, 1>{}, yb);
+            const bool oka = trail_row(edge_tag, border_tag, std::integral_constant<int, LO - 2 * NS>{}, e - 2 * NS, std::integral_constant<int, 0>{}, ya);
+            const int rrA = e - 2 * NS, pA = p0 + rrA, cp = pA >> 1;
+            const int cq = (qs >> 1) + lane;                                   // the lane's coarse column (fine columns 2 cq, 2 cq + 1)
+            const double wR = (EDGE && cq + 1 >= ncj) ? 1.0 : 0.5;             // the last coarse column takes its orphan right neighbour whole
+            const double wD = (EDGE && cp + 1 >= nci) ? 1.0 : 0.5;             // ... the last coarse row likewise (pweight)
+            double cv[3];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                double2 ra = {0.0, 0.0}, rb = {0.0, 0.0};
+                if (EDGE ? (oka && pair_ok) : true) { ra.x = BCo[f].x - ya[f].x; ra.y = BCo[f].y - ya[f].y; }
+                if (EDGE ? (okb && pair_ok) : true) { rb.x = BC[0][1][f].x - yb[f].x; rb.y = BC[0][1][f].y - yb[f].y; }
+                // columns 2 cq - 1 (the left lane's odd column), 2 cq, 2 cq + 1
+                const double ha = fma(0.5, lane_shr1(ra.y), fma(wR, ra.y, ra.x));
+                const double hb = fma(0.5, lane_shr1(rb.y), fma(wR, rb.y, rb.x));
+                cv[f] = 0.25 * fma(0.5, hprev[f], fma(wD, hb, ha));
+                hprev[f] = hb;
+            }
+            const bool own = st_ok && rrA >= 0 && rrA < TI && pA < ni && (EDGE ? (cq < ncj && cp < nci) : true);
+            if (own) {
+                ET* bc = reinterpret_cast<ET*>(tr.v) + (size_t)pair * 3 * ncpts + (size_t)cp * ncj + cq;
+                bc[0] = (ET)cv[0]; bc[ncpts] = (ET)cv[1]; bc[2 * ncpts] = (ET)cv[2];
+            }
+#pragma unroll
+            for (int f = 0; f < 3; ++f) BCo[f] = BC[0][0][f];                  // this step's row e - 2 is the next step's row e - 4
         }
         // ---- (4) write-out of rows e - 2 NS, e - 2 NS + 1
 #pragma unroll
@@ -666,7 +711,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
         const double a0 = wave_sum(bss);
         if (lane == 0) bsrc.partials[((size_t)pair * 3) * ((size_t)nx * ny) + (size_t)by * nx + bx] = a0;
     }
-    if constexpr (TRAIL != 0) {   // per-block partial sums of the dot products
+    if constexpr (TRAIL == 1) {   // per-block partial sums of the dot products
         const double a0 = wave_sum(ts0), a1 = wave_sum(ts1);
         if (lane == 0 && tr.partials) {
             const int nblk = nx * ny, blk = by * nx + bx;

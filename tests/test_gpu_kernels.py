@@ -484,7 +484,7 @@ def test_vector_updates_folded_into_the_first_pass_of_the_cycle(native, monkeypa
     """VOF_FUSE_B=1 (include/vof.h): the BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) are formed inside the
     first pre-smoothing pass of the cycle that consumes them (k_sweep0r, BF = 1 / 2) by the operations of k_update_s /
     k_update_p.  Same iteration counts, the same solution up to the summation order of (s, s), fewer launches of the vector
-    class; the default (b read once and handed on in registers, BF = 3) against VOF_S0R_BCARRY=0 is bit-identical."""
+    class."""
     mv = make_case("texture", (200, 264), 4, 5)
     p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9)
 
@@ -495,14 +495,32 @@ def test_vector_updates_folded_into_the_first_pass_of_the_cycle(native, monkeypa
             return out, s.profile_get("vector", 0)[0], s.profile_get("gs0", 0)[0]
 
     ref, nvec_ref, ngs_ref = run()
-    monkeypatch.setenv("VOF_S0R_BCARRY", "0")
-    twice, _, _ = run()
-    for a, b in zip(twice[:4], ref[:4]):
-        np.testing.assert_array_equal(a, b)
-    monkeypatch.delenv("VOF_S0R_BCARRY")
     monkeypatch.setenv("VOF_FUSE_B", "1")
     got, nvec, ngs = run()
     assert ngs == ngs_ref and nvec < nvec_ref - 2
     assert (got[4]["iterations"] == ref[4]["iterations"]).all() and got[4]["converged"].all()
     for a, b in zip(got[:4], ref[:4]):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape,npairs", [((66, 66), 2), ((140, 270), 1), ((12, 300), 1), ((300, 402), 2), ((258, 130), 1)])
+@pytest.mark.parametrize("vcycle_precision", [0, 3])
+def test_coarse_rhs_from_the_pre_smoothing_pass(native, monkeypatch, shape, npairs, vcycle_precision):
+    """Level 0: the coarse right-hand side R (b - A x) is the trailing stage of the pre-smoothing pass (k_sweep0r, TRAIL = 2)
+    instead of a pass of k_stream_resrestrict0 over x, b and the image (VOF_FUSE_RR=0).  Same cycle up to the summation order
+    of the restriction (float32 coarse right-hand sides: up to their rounding); several strips / bands, short and narrow grids."""
+    mv = make_case("texture", shape, npairs, 11)
+    p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, vcycle_precision=vcycle_precision)
+
+    def cycle():
+        with native.Solver(shape[0], shape[1], npairs) as s:
+            s.debug_setup(mv, p)
+            s.profile_enable(True)
+            e = s.debug_vcycle(s.debug_rhs())
+            return e, s.profile_get("apply0", 0)[0]
+
+    fused, n_apply = cycle()
+    monkeypatch.setenv("VOF_FUSE_RR", "0")
+    plain, n_apply_plain = cycle()
+    assert n_apply == n_apply_plain - 1          # the stand-alone residual + restriction launch is gone
+    assert relerr(fused, plain) < (1e-11 if vcycle_precision == 0 else 2e-6)
