@@ -127,8 +127,10 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *                              (default: k_sweep0m, two sweeps per pass)
  *   VOF_SWEEP0R=0              level 0, float64 vectors: the LDS-ring pass k_sweep0m instead of the register-resident k_sweep0r
  *   VOF_SWEEP0R_MIN_BLOCKS=n   ... k_sweep0r from n one-wave blocks per launch on (default 512; smaller launches use k_sweep0m)
- *   VOF_FUSE_B=1               experiment: the BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) are formed inside the
- *                              first pre-smoothing pass of the cycle that consumes them (same bits; measured neutral, default off)
+ *   VOF_FUSE_B=0               the BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) by their stand-alone kernels instead
+ *                              of inside the first pre-smoothing pass of the cycle that consumes them (same bits)
+ *   VOF_FUSE_RR=0              level 0: the coarse right-hand side R (b - A x) by the stand-alone residual + restriction kernel instead
+ *                              of as the trailing stage of the pre-smoothing pass
  *   VOF_SWEEP0P=0              level 0, float32 vectors: k_sweep0 (float64 arithmetic) instead of the packed-float32 k_sweep0p
  *   VOF_PRECOND_QUIRKS=hs      experiment: hierarchy (h) / smoother (s) of the preconditioner with (1) or without (0) the 'dy' == 'dx' quirk
  *   VOF_COARSEST_MAX=3..9      coarsen until max(n_i, n_j) <= this (default 5); changes the hierarchy depth, hence iteration counts

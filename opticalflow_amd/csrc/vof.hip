@@ -156,7 +156,7 @@ struct vof_ctx {
     bool fuse_rr = true;        // VOF_FUSE_RR=0: the stand-alone kernel k_stream_resrestrict0
     void* rr_out = nullptr;     // coarse right-hand side to write (nullptr: not requested)
     bool rr_f32 = false, rr_done = false;
-    bool fuse_b = false;        // VOF_FUSE_B=1 (experiment, measured neutral: DESIGN.md 3.0): fold k_update_s / k_update_p into that pass
+    bool fuse_b = true;         // VOF_FUSE_B=0: the stand-alone kernels k_update_s / k_update_p
     int bf_mode = 0;            // 0: none pending; 1: s = r - alpha v (+ (s, s), half-step test); 2: p = r + beta (p_old - omega v)
     S0BSrc bf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int trail_nblk = 0;         // per-pair partial sums the fused pass wrote
@@ -617,7 +617,7 @@ inline S0Geo s0_geometry(const vof_ctx* c, int rows, int NSW, bool trail) {
 // right-hand side is folded into that pass (the conditions mirror vcycle_t -> smooth_level_t -> sweep_level_t).
 inline bool fold_b_usable(const vof_ctx* c) {
     return c->fuse_b && !c->direct_on && !c->vfloat && c->L.size() > 1 && c->tail_first != 0 && c->fused && c->prm.nu_pre >= 2 &&
-           sweep0m_usable(c) && c->sweep0m_pairs && s0_geometry(c, c->L[0].ni, 2, false).s0r;
+           sweep0m_usable(c) && c->sweep0m_pairs && s0_geometry(c, c->L[0].ni, 2, false).s0r && s0_geometry(c, c->L[0].ni, 2, true).s0r;
 }
 
 // One full 4-colour sweep x_in -> x_out (x_in == nullptr: zero initial guess); reverse = colours 3,2,1,0.
@@ -638,8 +638,7 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
             const int NSW = nsweeps >= 2 ? 2 : 1;
             const bool trail = with_trail && x_in != nullptr;
             // the coarse right-hand side R (b - A x_out) as the trailing stage of the two-sweep pass from zero (k_sweep0r only)
-            const bool rr = c->rr_out && !x_in && NSW == 2 && !po && !ecoarse && !c->bf_mode && VOF_S0R_BCARRY &&
-                            s0_geometry(c, rows, NSW, true).s0r;
+            const bool rr = c->rr_out && !x_in && NSW == 2 && !po && !ecoarse && VOF_S0R_BCARRY && s0_geometry(c, rows, NSW, true).s0r;
             const S0Geo geo = s0_geometry(c, rows, NSW, trail || rr);
             const int nx = geo.nx, TI = geo.TI, ny = geo.ny;
             dim3 g((unsigned)nx * ny * np, 1, 1);
@@ -651,13 +650,19 @@ void sweep_level_t(vof_ctx* c, int l, const VT* x_in, VT* x_out, const VT* b, bo
                 const int mode = c->bf_mode;
                 c->bf_mode = 0;
                 Fine0 f0{c->frames, frame_stride(c), c->Nj, c->prm.speed_alpha, c->prm.remodelling_alpha, 1, c->pp};
-                S0Trail tr{nullptr, nullptr, 0, nullptr};
-                const size_t ldsr = S0R<2, 0>::LDS_TOTAL;
-                {   // I + r(3) + v(3) (+ p_old(3)) in, x(3) + b(3) out
-                    const double moved = (8.0 + (mode == 2 ? 15.0 : 12.0) * 8.0) * lv.npts;
-                    Prof p(c, VOF_K_GS0, 0, moved + 80.0 * lv.npts, moved);
-                    if (mode == 1) k_sweep0r<2, false, true, 0, double, 0, 1, 1><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 0, nx, ny, np, nullptr, x_out, b, active, nullptr, 0, 0, tr, 0, 0, c->bf);
-                    else k_sweep0r<2, false, true, 0, double, 0, 1, 2><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 0, nx, ny, np, nullptr, x_out, b, active, nullptr, 0, 0, tr, 0, 0, c->bf);
+                S0Trail tr{rr ? (double*)c->rr_out : nullptr, nullptr, 0, nullptr};
+                const size_t ldsr = rr ? S0R<2, 2>::LDS_TOTAL : S0R<2, 0>::LDS_TOTAL;
+                const int kci = c->L[1].ni, kcj = c->L[1].nj;
+                {   // I + r(3) + v(3) (+ p_old(3)) in, x(3) + b(3) out (+ the coarse right-hand side)
+                    const double cb = rr ? (c->rr_f32 ? 12.0 : 24.0) * c->L[1].npts : 0.0;
+                    const double moved = (8.0 + (mode == 2 ? 15.0 : 12.0) * 8.0) * lv.npts + cb;
+                    Prof p(c, VOF_K_GS0, 0, moved + 80.0 * lv.npts + (rr ? 56.0 * lv.npts : 0.0), moved);
+#define VOF_LAUNCH_BF(TR_, ET_, BF_) k_sweep0r<2, false, true, TR_, ET_, 0, 1, BF_><<<g, 64, ldsr, c->stream>>>(f0, lv.ni, lv.nj, TI, 0, nx, ny, np, nullptr, x_out, b, active, nullptr, kci, kcj, tr, 0, 0, c->bf)
+                    if (rr && c->rr_f32) { if (mode == 1) VOF_LAUNCH_BF(2, float, 1); else VOF_LAUNCH_BF(2, float, 2); }
+                    else if (rr) { if (mode == 1) VOF_LAUNCH_BF(2, double, 1); else VOF_LAUNCH_BF(2, double, 2); }
+                    else { if (mode == 1) VOF_LAUNCH_BF(0, double, 1); else VOF_LAUNCH_BF(0, double, 2); }
+#undef VOF_LAUNCH_BF
+                    if (rr) c->rr_done = true;
                 }
                 if (mode == 1) {   // (s, s): stopping rule at the half step; pairs done there get their x += alpha y and leave the cycle
                     const size_t len = 3 * lv.npts;

@@ -88,11 +88,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
     const ET* __restrict__ ecoarse, int nci, int ncj, S0Trail tr, int skip_first = 0, int skip_count = 0,
     S0BSrc bsrc = S0BSrc{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}) {
     static_assert(BF == 0 || NS == 2, "b is handed from the first sweep's stages to the second's");
-    static_assert(BF == 0 || BF == 3 || (FROM_ZERO && !EC && TRAIL == 0 && PO == 0), "the folded vector update belongs to the first pre-smoothing pass");
+    static_assert(BF == 0 || BF == 3 || (FROM_ZERO && !EC && TRAIL != 1 && PO == 0), "the folded vector update belongs to the first pre-smoothing pass");
     // TRAIL = 2: the trailing stage forms the RESIDUAL b - A x_out of the rows that have just become final and restricts it (full
     // weighting, R = P^T / 4, as k_stream_resrestrict0) - the coarse right-hand side comes out of the pre-smoothing pass and the
     // residual + restriction kernel's pass over x, b and the image is gone.  ET = type of the coarse right-hand side, written to tr.v.
-    static_assert(TRAIL != 2 || (FROM_ZERO && !EC && PO == 0 && BF == 3), "the residual + restriction stage belongs to the pre-smoothing pass");
+    static_assert(TRAIL != 2 || (FROM_ZERO && !EC && PO == 0 && BF != 0), "the residual + restriction stage belongs to the pre-smoothing pass");
     constexpr bool RR = TRAIL == 2;
     // (skip_first, skip_count: the strips [skip_first, skip_first + skip_count) belong to another launch - k_sweep0p takes the
     // interior strips in its mode -; nx counts the strips of THIS launch)

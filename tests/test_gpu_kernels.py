@@ -481,10 +481,10 @@ def test_debug_switches_guard_regions_poison_and_batch_time(native, monkeypatch)
 
 @pytest.mark.gpu
 def test_vector_updates_folded_into_the_first_pass_of_the_cycle(native, monkeypatch):
-    """VOF_FUSE_B=1 (include/vof.h): the BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) are formed inside the
-    first pre-smoothing pass of the cycle that consumes them (k_sweep0r, BF = 1 / 2) by the operations of k_update_s /
-    k_update_p.  Same iteration counts, the same solution up to the summation order of (s, s), fewer launches of the vector
-    class."""
+    """The BiCGStab updates s = r - alpha v and p = r + beta (p - omega v) are formed inside the first pre-smoothing pass of the
+    cycle that consumes them (k_sweep0r, BF = 1 / 2) by the operations of k_update_s / k_update_p (VOF_FUSE_B=0: those
+    kernels).  Same iteration counts, the same solution up to the summation order of (s, s), fewer launches of the vector
+    class - with and without the residual + restriction stage in the same pass."""
     mv = make_case("texture", (200, 264), 4, 5)
     p = native.default_params(speed_alpha=1.0, remodelling_alpha=1e4, rtol=1e-9)
 
@@ -494,13 +494,16 @@ def test_vector_updates_folded_into_the_first_pass_of_the_cycle(native, monkeypa
             out = s.solve_host(mv, p)
             return out, s.profile_get("vector", 0)[0], s.profile_get("gs0", 0)[0]
 
-    ref, nvec_ref, ngs_ref = run()
-    monkeypatch.setenv("VOF_FUSE_B", "1")
-    got, nvec, ngs = run()
-    assert ngs == ngs_ref and nvec < nvec_ref - 2
-    assert (got[4]["iterations"] == ref[4]["iterations"]).all() and got[4]["converged"].all()
-    for a, b in zip(got[:4], ref[:4]):
-        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+    for rr in ("1", "0"):
+        monkeypatch.setenv("VOF_FUSE_RR", rr)
+        monkeypatch.setenv("VOF_FUSE_B", "0")
+        ref, nvec_ref, ngs_ref = run()
+        monkeypatch.delenv("VOF_FUSE_B")
+        got, nvec, ngs = run()
+        assert ngs == ngs_ref and nvec < nvec_ref - 2
+        assert (got[4]["iterations"] == ref[4]["iterations"]).all() and got[4]["converged"].all()
+        for a, b in zip(got[:4], ref[:4]):
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("shape,npairs", [((66, 66), 2), ((140, 270), 1), ((12, 300), 1), ((300, 402), 2), ((258, 130), 1)])
