@@ -1433,8 +1433,9 @@ int solve_batch(vof_ctx* c, const double* frames_dev, int np, double* vx, double
     // has not converged after MG_ATTEMPT_CAP of them is handed to the direct preconditioner, which settles it in one or two
     struct MaxItGuard { vof_params& p; int saved; ~MaxItGuard() { p.max_iterations = saved; } } max_it_guard{c->prm, c->prm.max_iterations};
     constexpr int MG_ATTEMPT_CAP = 150;
-    // (images up to ~530 pixels wide, where the direct re-solve takes seconds: 3.3 s per pair at 514^2)
-    if (P.preconditioner == 2 && !c->direct_on && c->L.size() > 1 && P.max_iterations > MG_ATTEMPT_CAP && 3 * c->L[0].nj <= 1600 &&
+    // (images up to 1026 pixels wide - the reference's real-data sizes -: the direct re-solve takes 3.3 s per pair at 514^2, 18 s and
+    // 79 GB at 1026^2, the multigrid attempt to 1000 iterations as long again)
+    if (P.preconditioner == 2 && !c->direct_on && c->L.size() > 1 && P.max_iterations > MG_ATTEMPT_CAP && 3 * c->L[0].nj <= 3100 &&
         direct_ok_for_fallback(c))
         c->prm.max_iterations = MG_ATTEMPT_CAP;
     if (stats) HIPCHK(hipEventRecord(c->ev_batch[0], c->stream));

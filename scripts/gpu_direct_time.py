@@ -1,5 +1,5 @@
 """Time and memory of the direct preconditioner with the in-house dense inverses:
-usage: python scripts/gpu_direct_time.py n [alpha beta]  (8-bit texture, one pair, use_direct_solver=True)"""
+usage: python scripts/gpu_direct_time.py n [alpha beta [calls]]  (8-bit texture, one pair, use_direct_solver=True)"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -10,7 +10,7 @@ alpha = float(sys.argv[2]) if len(sys.argv) > 2 else 1e4
 beta = float(sys.argv[3]) if len(sys.argv) > 3 else 1e2
 mv = np.round(texture_stack_numpy(n, 2, 5) * 255.0)
 f0, _ = _native.device_memory(0)
-for rep in range(2):
+for rep in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
     t0 = time.time()
     r = of.variational_optical_flow(mv, speed_alpha=alpha, remodelling_alpha=beta, use_direct_solver=True, return_stats=True, max_pairs_in_flight=1)
     dt = time.time() - t0

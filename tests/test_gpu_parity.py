@@ -531,6 +531,23 @@ def test_real_data_regime_at_514_by_the_cpu_residual(of):
     assert rel == pytest.approx(st["relative_residual"][0], rel=1e-4)
 
 
+def test_real_data_regime_at_1026_by_the_cpu_residual(of):
+    """Regime T at 1026 x 1026 - the largest frame size of the reference's scripts (3072 unknowns per image row: the blocked
+    inverse on the FP64 matrix cores, 79 GB of inverse Schur blocks for the pair) -, default arguments: the multigrid attempt
+    is handed over after 150 Krylov steps, the direct preconditioner settles the pair in one step (about 18 s)."""
+    movie = np.round(orc.make_texture_stack(1026, 2, seed=5) * 255.0)
+    res = of.variational_optical_flow(movie, speed_alpha=1e4, remodelling_alpha=1e2, return_stats=True)
+    st = res["stats"]
+    assert st["converged"].all(), st
+    xi = np.stack([res[f][0] for f in ("v_x", "v_y", "remodelling")])[:, 1:-1, 1:-1]
+    b = orc.rhs_interior(movie[0], movie[1])
+    r = b - orc.apply_operator_interior(movie[0], xi, 1e4, 1e2)
+    rel = np.linalg.norm(r) / np.linalg.norm(b)
+    assert rel <= 1e-6 * (1 + 1e-6), rel
+    assert rel == pytest.approx(st["relative_residual"][0], rel=1e-4)
+    of.release_device_memory()
+
+
 def test_parameter_sweep_of_the_reference_script_on_8bit_data(of):
     """AVOF.py:608-615: vary_regularisation over logspace(-1, 4) x logspace(-1, 4) on a down-sampled 8-bit stack with
     smoothing_sigma=1 and use_direct_solver=True - almost all of that grid lies in the regimes the multigrid cycle does not
