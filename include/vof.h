@@ -151,7 +151,10 @@ int vof_default_params(vof_params* p, size_t struct_size);
  *   VOF_DEBUG_CANARY=1         every device buffer of the context is allocated between two 4-KiB guard regions of a known byte
  *                              pattern, checked by vof_debug_check_canaries and vof_destroy (out-of-bounds WRITES are named
  *                              by buffer and offset)
- *   VOF_DEBUG_ALLOC_LOG=1      base, end, size and name of every device buffer on stderr (maps a faulting address to a buffer) */
+ *   VOF_DEBUG_POISON=1         every device buffer is filled with 0xFF bytes (NaN as floating point) when it is allocated: a read of
+ *                              workspace nothing has written shows up as a non-finite result
+ *   VOF_DEBUG_ALLOC_LOG=1      base, end, size and name of every device buffer on stderr (maps a faulting address to a buffer)
+ *   VOF_TRACE_HOST=1           vof_solve_stack_host: timeline of the host pipeline (page touching, pinning, copies, batches) on stderr */
 
 /* One context = one device = one host thread at a time.  Owns device workspaces for images of
  * (n_i, n_j) and up to max_pairs_in_flight frame pairs solved concurrently (batch dimension).

@@ -23,8 +23,15 @@
 //    other level-0 smoother: results are bit-identical to the per-colour kernels (the tests compare bits).
 //
 // Variants as in k_sweep0m: FROM_ZERO (first pre-smoothing pass), EC (x_in + P e: the coarse-grid correction interpolated
-// into the rows as they enter the window), TRAIL (v = A x_out with the Krylov dot products from the rows that have just
-// become final; needs one more live row, not four).
+// into the rows as they enter the window), TRAIL = 1 (v = A x_out with the Krylov dot products from the rows that have just
+// become final; needs one more live row, not four).  Beyond k_sweep0m (second half of round 3):
+//  * the diagonal blocks of the first sweep's rows go through a second wave-private LDS ring to the second sweep's stages and to
+//    the trailing stage (S0R::DC, gs0_point<.., DC>): a third of an update's FP64 instructions is not repeated;
+//  * TRAIL = 2: the trailing stage forms the residual b - A x_out and restricts it - the coarse right-hand side leaves the
+//    pre-smoothing pass, the residual + restriction kernel's pass over x, b and the image is gone;
+//  * BF: the pass from zero forms its own right-hand side (s = r - alpha v with (s, s), or p = r + beta (p - omega v): the
+//    BiCGStab updates that would have written it) or reads it once, and hands the rows from the first sweep's stages to the
+//    second's in registers.
 #pragma once
 #include "vof_device.hpp"
 
