@@ -506,7 +506,8 @@ def test_vector_updates_folded_into_the_first_pass_of_the_cycle(native, monkeypa
             np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("shape,npairs", [((66, 66), 2), ((140, 270), 1), ((12, 300), 1), ((300, 402), 2), ((258, 130), 1)])
+@pytest.mark.parametrize("shape,npairs", [((66, 66), 2), ((140, 270), 1), ((12, 300), 1), ((300, 402), 2), ((258, 130), 1),
+                                          ((67, 66), 1), ((141, 270), 2), ((263, 14), 1)])   # the last three: odd row counts
 @pytest.mark.parametrize("vcycle_precision", [0, 3])
 def test_coarse_rhs_from_the_pre_smoothing_pass(native, monkeypatch, shape, npairs, vcycle_precision):
     """Level 0: the coarse right-hand side R (b - A x) is the trailing stage of the pre-smoothing pass (k_sweep0r, TRAIL = 2)
