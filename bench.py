@@ -399,6 +399,39 @@ def main():
             out["variants"]["time_varying_flow_wobble_0.3"] = timed(params, wob)
             out["variants"]["time_varying_flow_wobble_0.3_cold"] = timed(_native.default_params(vcycle_precision=vp, coarse_precision=cp, **cold), wob)
             del wob
+        if n_chunks == 1 and P >= 8:
+            # two contexts, each with one half of the stack, on their own streams and host threads at the same time: the
+            # instruction-bound passes of one half run over the bandwidth-bound kernels of the other.
+            # Informational: per-launch times overlap in this mode, so the roofline figures above are taken with one context.
+            import threading
+            cuts = [0, (P + 1) // 2, P]
+            subs = [_native.Solver(n, n, cuts[i + 1] - cuts[i], device=local_rank) for i in range(2)]
+
+            def both():
+                res = [None, None]
+
+                def work(i):
+                    a, b = cuts[i], cuts[i + 1]
+                    o = outs[0]
+                    res[i] = subs[i].solve_dev(movies[0][a:b + 1], b - a + 1, params, o[0][a:b], o[1][a:b], o[2][a:b], o[3][a:b], stats=True)
+                th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                return np.concatenate(res)
+            both()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            stv = both()
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t1
+            out["variants"]["two_contexts_at_once"] = {
+                "value": P / d, "unit": "frame-pairs/s", "iterations_mean": float(stv["iterations"].mean()),
+                "relres_max": float(stv["relative_residual"].max()), "converged": bool(stv["converged"].all()),
+                "what": "the stack as two halves solved at the same time by two contexts (two streams, two host threads)"}
+            for sub in subs:
+                sub.close()
     if world == 1 and not use_dist and not args.no_variants:
         # the reference's second consumer of the path: vary_regularisation (OF.py:1918-1998) in the shape of its own sweep,
         # AVOF.py:608-615 - a 20 x 20 logspace(-1, 4) grid of (speed_alpha, remodelling_alpha) on a down-sampled 8-bit
