@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvof.so")
 SOURCES = ["vof.hip"]
-DEPS = ["vof.hip", "vof_device.hpp", "vof_direct.hpp", os.path.join("..", "..", "include", "vof.h")]
+# every source and header of csrc/ (a header missing from this list once left a stale library in the tree) + the public header
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))) + [os.path.join("..", "..", "include", "vof.h")]
 
 
 def needs_build():

@@ -55,6 +55,9 @@ __device__ __forceinline__ double lane_shl1(double v) {
 #ifndef VOF_S0R_DCACHE
 #define VOF_S0R_DCACHE 1
 #endif
+#ifndef VOF_S0R_BRING
+#define VOF_S0R_BRING 1         // post-smoothing pass: b handed from sweep to sweep through LDS (S0R::BL); 0: read once per sweep
+#endif
 #ifndef VOF_S0R_BCARRY
 #define VOF_S0R_BCARRY 1        // two-sweep pass from zero: b is read once and handed on in registers (BF = 3); 0: read once per sweep
                                 // (the passes with one wave per SIMD lose 5 % with it - measured -, so only that one)
@@ -73,10 +76,14 @@ template <int NS, int TRAIL = 0> struct S0R {
     static constexpr int LDS_BYTES = NRI * IRB;      // the image ring (all k_sweep0p uses)
     // the diagonal blocks of the first sweep's rows, handed on to the second sweep (and the trailing product) through LDS: rows
     // e - 2 NS + 1 - EXT .. e, an even number of slots (the ring turns by two rows per step); a row = 4 values x 64 lanes x 16 B
-    static constexpr bool DC = (VOF_S0R_DCACHE != 0) && NS == 2;
+    // BL (post-smoothing pass, TRAIL = 1): the rows of b go from the first sweep's stages to the second's through LDS instead of
+    // being read again (two steps x two row parities = four slots of 3 x 64 x 16 B); takes the room of the diagonal-block ring there
+    static constexpr bool BL = (VOF_S0R_BRING != 0) && NS == 2 && TRAIL == 1;
+    static constexpr bool DC = (VOF_S0R_DCACHE != 0) && NS == 2 && !BL;
     static constexpr int ND = DC ? 2 * NS + 2 * EXT : 0;
     static constexpr int DRB = 4 * 64 * 16;
-    static constexpr int LDS_TOTAL = LDS_BYTES + ND * DRB;
+    static constexpr int NBL = BL ? 4 : 0, BRB = 3 * 64 * 16;
+    static constexpr int LDS_TOTAL = LDS_BYTES + ND * DRB + NBL * BRB;
 };
 
 struct S0RRow { double2 u, w, g; };   // one x row of the strip: .x = column 2 lane, .y = column 2 lane + 1
@@ -111,6 +118,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
     extern __shared__ double sw_lds[];
     char* iring = reinterpret_cast<char*>(sw_lds);
     char* dring = iring + G::LDS_BYTES;
+    char* bring = dring + ND * DRB;
+    constexpr bool BL = G::BL && BF == 0;
+    int bph = 0;                                                            // BL: this step's slot pair (toggles every step)
     const unsigned nblocks = (unsigned)nx * ny * nz;
     unsigned lb = blockIdx.x;
     if ((nblocks & 7u) == 0) lb = (lb & 7u) * (nblocks >> 3) + (lb >> 3);   // XCD-aware remap, see k_sweep
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                     }
                 }
             }
-        } else {
+        } else if constexpr (!(BL && st >= 2)) {   // (BL: stages 2, 3 take their rows out of LDS)
             if (EDGE) B[st][0] = B[st][1] = B[st][2] = double2{0.0, 0.0};
             if (EDGE ? (rowok && pair_ok) : true) {
                 const double* brow = bp + (size_t)p * nj + qg;
@@ -551,6 +561,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                 if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, bs);
             } else if constexpr (BF != 0) {
                 if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, BC[0][ST - 2]);
+            } else if constexpr (BL && ST < 2) {
+                if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, B[ST]);
+                char* bw = bring + (ST * 2 + bph) * G::BRB + lane * 16;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) *reinterpret_cast<double2*>(bw + f * 1024) = B[ST][f];
+            } else if constexpr (BL) {
+                double2 bl[3];
+                const char* br = bring + ((ST - 2) * 2 + (bph ^ 1)) * G::BRB + lane * 16;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) bl[f] = *reinterpret_cast<const double2*>(br + f * 1024);
+                if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, bl);
             } else {
                 if (rowok) stage(edge_tag, border_tag, std::integral_constant<int, LO - ST>{}, rr, B[ST]);
             }
@@ -629,6 +650,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
             islot += 2;
             if (islot >= NRI) islot -= NRI;
             if (DC) { dslot += 2; if (dslot >= ND) dslot -= ND; }
+            if (BL) bph ^= 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS operations of a wave execute in order; keeps the compiler from
             __builtin_amdgcn_wave_barrier();                         // moving next step's reads above these writes
         }
