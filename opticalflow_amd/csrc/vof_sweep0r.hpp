@@ -75,12 +75,13 @@ template <int NS, int TRAIL = 0> struct S0R {
     static constexpr int NRI = LO + 2;               // image ring rows: e - LO .. e + 1; rows e + 2, e + 3 replace the two oldest
     static constexpr int LDS_BYTES = NRI * IRB;      // the image ring (all k_sweep0p uses)
     // the diagonal blocks of the first sweep's rows, handed on to the second sweep (and the trailing product) through LDS: rows
-    // e - 2 NS + 1 - EXT .. e, an even number of slots (the ring turns by two rows per step); a row = 4 values x 64 lanes x 16 B
+    // e - 2 NS + 1 - EXT .. e = 2 NS + EXT slots (slot = row modulo their number); a row = 4 values x 64 lanes x 16 B
     // BL (post-smoothing pass, TRAIL = 1): the rows of b go from the first sweep's stages to the second's through LDS instead of
-    // being read again (two steps x two row parities = four slots of 3 x 64 x 16 B); takes the room of the diagonal-block ring there
+    // being read again (two steps x two row parities = four slots of 3 x 64 x 16 B).  It takes the room of the diagonal-block ring
+    // there: with both (40 160 B per wave) only three waves fit a CU and the pass loses 8 % (measured)
     static constexpr bool BL = (VOF_S0R_BRING != 0) && NS == 2 && TRAIL == 1;
     static constexpr bool DC = (VOF_S0R_DCACHE != 0) && NS == 2 && !BL;
-    static constexpr int ND = DC ? 2 * NS + 2 * EXT : 0;
+    static constexpr int ND = DC ? 2 * NS + EXT : 0;
     static constexpr int DRB = 4 * 64 * 16;
     static constexpr int NBL = BL ? 4 : 0, BRB = 3 * 64 * 16;
     static constexpr int LDS_TOTAL = LDS_BYTES + ND * DRB + NBL * BRB;
