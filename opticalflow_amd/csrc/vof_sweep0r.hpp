@@ -58,6 +58,9 @@ __device__ __forceinline__ double lane_shl1(double v) {
 #ifndef VOF_S0R_BRING
 #define VOF_S0R_BRING 1         // post-smoothing pass: b handed from sweep to sweep through LDS (S0R::BL); 0: read once per sweep
 #endif
+#ifndef VOF_S0R_BL_DC
+#define VOF_S0R_BL_DC 1         // ... and a four-row diagonal-block ring beside it (0: no diagonal-block ring in that pass)
+#endif
 #ifndef VOF_S0R_BCARRY
 #define VOF_S0R_BCARRY 1        // two-sweep pass from zero: b is read once and handed on in registers (BF = 3); 0: read once per sweep
                                 // (the passes with one wave per SIMD lose 5 % with it - measured -, so only that one)
@@ -77,11 +80,13 @@ template <int NS, int TRAIL = 0> struct S0R {
     // the diagonal blocks of the first sweep's rows, handed on to the second sweep (and the trailing product) through LDS: rows
     // e - 2 NS + 1 - EXT .. e = 2 NS + EXT slots (slot = row modulo their number); a row = 4 values x 64 lanes x 16 B
     // BL (post-smoothing pass, TRAIL = 1): the rows of b go from the first sweep's stages to the second's through LDS instead of
-    // being read again (two steps x two row parities = four slots of 3 x 64 x 16 B).  It takes the room of the diagonal-block ring
-    // there: with both (40 160 B per wave) only three waves fit a CU and the pass loses 8 % (measured)
+    // being read again (two steps x two row parities = four slots of 3 x 64 x 16 B).  With the full diagonal-block ring beside it
+    // (40 160 B per wave) only three waves fit a CU and the pass loses 8 % (measured); so there the ring holds four rows - enough
+    // for the second sweep's stages - and the trailing stage computes its diagonal blocks itself (DCT)
     static constexpr bool BL = (VOF_S0R_BRING != 0) && NS == 2 && TRAIL == 1;
-    static constexpr bool DC = (VOF_S0R_DCACHE != 0) && NS == 2 && !BL;
-    static constexpr int ND = DC ? 2 * NS + EXT : 0;
+    static constexpr bool DC = (VOF_S0R_DCACHE != 0) && NS == 2 && (!BL || VOF_S0R_BL_DC);
+    static constexpr bool DCT = DC && !BL;            // the trailing stage takes the diagonal blocks out of the ring too
+    static constexpr int ND = DC ? 2 * NS + (DCT ? EXT : 0) : 0;
     static constexpr int DRB = 4 * 64 * 16;
     static constexpr int NBL = BL ? 4 : 0, BRB = 3 * 64 * 16;
     static constexpr int LDS_TOTAL = LDS_BYTES + ND * DRB + NBL * BRB;
@@ -448,9 +453,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
         const double iuA = LD(iu, ie), iuB = LD(iu, io), iuC = LD(iu, ie + 8), iuD = LD(iu, io + 8);
         const double icA = LD(ic, ie), icB = LD(ic, io), icC = LD(ic, ie + 8), icD = LD(ic, io + 8);
         const double idA = LD(id, ie), idB = LD(id, io), idC = LD(id, ie + 8), idD = LD(id, io + 8);
-        constexpr int DCT = DC ? 2 : 0;
+        constexpr int DCT = G::DCT ? 2 : 0;
         double2 dq[3] = {{0, 0}, {0, 0}, {0, 0}};                           // axx, ayy, c of the row (stored by the first sweep's stage)
-        if constexpr (DC) {
+        if constexpr (G::DCT) {
             const char* dr = drow(LO - jc);
 #pragma unroll
             for (int v = 0; v < 3; ++v) dq[v] = *reinterpret_cast<const double2*>(dr + v * 1024);
