@@ -303,10 +303,10 @@ __device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double 
     const double P = k.P;
     const double hPDx = P * k.Dx / 2, hPDy = P * k.Dy / 2, qPP = P * P / 4, hP = P / 2;
     y0 = (P * (P - k.Dx) + alpha) * n.u[1] + (P * (P + k.Dx) + alpha) * n.u[7] + alpha * (n.u[3] + n.u[5]) +
-         hPDx * (n.w[5] - n.w[3]) + hPDy * (n.w[7] - n.w[1]) + qPP * (n.w[0] + n.w[8] - n.w[2] - n.w[6]) +
+         hPDx * (n.w[5] - n.w[3]) + hPDy * (n.w[7] - n.w[1]) + qPP * ((n.w[8] - n.w[2]) - (n.w[6] - n.w[0])) +
          hP * (n.g[1] - n.g[7]);
     y1 = (P * (P - k.Dy) + alpha) * n.w[3] + (P * (P + k.Dy) + alpha) * n.w[5] + alpha * (n.w[1] + n.w[7]) +
-         hPDy * (n.u[7] - n.u[1]) + hPDx * (n.u[5] - n.u[3]) + qPP * (n.u[0] + n.u[8] - n.u[2] - n.u[6]) +
+         hPDy * (n.u[7] - n.u[1]) + hPDx * (n.u[5] - n.u[3]) + qPP * ((n.u[8] - n.u[2]) - (n.u[6] - n.u[0])) +
          hP * (n.g[3] - n.g[5]);
     y2 = beta * (n.g[1] + n.g[7] + n.g[3] + n.g[5]) + hP * (n.u[7] - n.u[1]) + hP * (n.w[5] - n.w[3]);
 }
@@ -330,10 +330,16 @@ __device__ __forceinline__ void offdiag0(const PixCoef& k, double alpha, double 
 // handed on from one sweep of a pass to the next: 1 = also store them to *dg, 2 = take them from *dg instead of computing them
 // (the same values by the same operations: the same bits; only im[1], im[4], im[7] - and im[3], im[5] without the quirk - are read).
 struct Diag0 { double axx, ayy, c, inv; };
-template <bool CORNERS, int ZERO = 0, int DC = 0>
+// PRE: the differences of the rows below and above are handed in (k_sweep0r forms them once per row for both of a lane's columns
+// and shifts the DIFFERENCES sideways: four lane-shifted words and four subtractions fewer per update).  The diagonal neighbours
+// enter only through  U4 = (u_dr - u_ur) - (u_dl - u_ul),  W4 likewise - differences of those column differences -, which is
+// why every kernel forms U4 / W4 in exactly this association: the same bits with and without PRE.
+struct VDiff0 { double du71, dw71, U4, W4; };
+template <bool CORNERS, int ZERO = 0, int DC = 0, int PRE = 0>
 __device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
                                           double alpha, double beta, double inv_g, int quirks, double b0, double b1,
-                                          double b2, double& u, double& w, double& gm, Diag0* dg = nullptr) {
+                                          double b2, double& u, double& w, double& gm, Diag0* dg = nullptr,
+                                          const VDiff0* vd = nullptr) {
     // Every fused multiply-add is written out and automatic contraction is off: the compiler's own fusion choices depend
     // on the surrounding code, and the per-colour kernel and the streaming kernel must round identically.
 #pragma clang fp contract(off)
@@ -353,14 +359,18 @@ __device__ __forceinline__ void gs0_point(const double* im, const Nbr& n, double
         const double y2 = fma(hP, dw53, beta * (n.g[3] + n.g[5]));
         r0 = b0 - y0a; r1 = b1 - (y1a + y1b); r2 = b2 - y2;
     } else {
-        const double du71 = n.u[7] - n.u[1], dw71 = n.w[7] - n.w[1];
-        double W4, U4;
-        if (CORNERS) {   // products with 1 or 2 are exact: same bits as the plain sums wherever no corner ghost is involved
-            W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
-            U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+        double du71, dw71, W4, U4;
+        if (PRE) {
+            du71 = vd->du71; dw71 = vd->dw71; U4 = vd->U4; W4 = vd->W4;
         } else {
-            W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
-            U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+            du71 = n.u[7] - n.u[1]; dw71 = n.w[7] - n.w[1];
+            if (CORNERS) {   // products with 1 or 2 are exact: same bits as the plain differences wherever no corner ghost is involved
+                W4 = (sDR * n.w[8] - sUR * n.w[2]) - (sDL * n.w[6] - sUL * n.w[0]);
+                U4 = (sDR * n.u[8] - sUR * n.u[2]) - (sDL * n.u[6] - sUL * n.u[0]);
+            } else {
+                W4 = (n.w[8] - n.w[2]) - (n.w[6] - n.w[0]);
+                U4 = (n.u[8] - n.u[2]) - (n.u[6] - n.u[0]);
+            }
         }
         if (ZERO == 3) {        // everything but the left / right neighbours
             const double y0a = A1 * (n.u[1] + n.u[7]);
@@ -3014,23 +3024,28 @@ template <int NS, int TRAIL = 0> struct S0M {
 
 // Full operator product (A x)(p, q) of level 0 at one point from the 3x3 neighbourhoods of the image and of x (ghosts folded
 // by the caller, corner factors applied here), in the style of gs0_point.
-template <bool CORNERS, int DC = 0>
+template <bool CORNERS, int DC = 0, int PRE = 0>
 __device__ __forceinline__ void apply0_point(const double* im, const Nbr& n, double sUL, double sUR, double sDL, double sDR,
                                              double alpha, double beta, int quirks, double& y0, double& y1, double& y2,
-                                             const Diag0* dg = nullptr) {
+                                             const Diag0* dg = nullptr, const VDiff0* vd = nullptr) {
     const double P = im[4];
     const double Dx = (im[7] - im[1]) * 0.5;
     const double Dy = quirks ? Dx : (im[5] - im[3]) * 0.5;
     const double PP = P * P, PDx = P * Dx, PDy = P * Dy, hP = 0.5 * P;
     const double A1 = PP + alpha, qPP = 0.25 * PP, hPDx = 0.5 * PDx, hPDy = 0.5 * PDy;
-    const double du71 = n.u[7] - n.u[1], du53 = n.u[5] - n.u[3], dw71 = n.w[7] - n.w[1], dw53 = n.w[5] - n.w[3];
-    double W4, U4;
-    if (CORNERS) {
-        W4 = sUL * n.w[0] + sDR * n.w[8] - sUR * n.w[2] - sDL * n.w[6];
-        U4 = sUL * n.u[0] + sDR * n.u[8] - sUR * n.u[2] - sDL * n.u[6];
+    const double du53 = n.u[5] - n.u[3], dw53 = n.w[5] - n.w[3];
+    double du71, dw71, W4, U4;
+    if (PRE) {   // (see gs0_point)
+        du71 = vd->du71; dw71 = vd->dw71; U4 = vd->U4; W4 = vd->W4;
     } else {
-        W4 = n.w[0] + n.w[8] - n.w[2] - n.w[6];
-        U4 = n.u[0] + n.u[8] - n.u[2] - n.u[6];
+        du71 = n.u[7] - n.u[1]; dw71 = n.w[7] - n.w[1];
+        if (CORNERS) {
+            W4 = (sDR * n.w[8] - sUR * n.w[2]) - (sDL * n.w[6] - sUL * n.w[0]);
+            U4 = (sDR * n.u[8] - sUR * n.u[2]) - (sDL * n.u[6] - sUL * n.u[0]);
+        } else {
+            W4 = (n.w[8] - n.w[2]) - (n.w[6] - n.w[0]);
+            U4 = (n.u[8] - n.u[2]) - (n.u[6] - n.u[0]);
+        }
     }
     double axx, ayy, c;
     if (DC == 2) {   // diagonal block handed on by the sweep stages (gs0_point: the same expressions)

@@ -321,6 +321,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
         const double iuA = LD(iu, ie), iuB = LD(iu, io), iuC = LD(iu, ie + 8), iuD = LD(iu, io + 8);
         const double icA = LD(ic, ie), icB = LD(ic, io), icC = LD(ic, ie + 8), icD = LD(ic, io + 8);
         const double idA = LD(id, ie), idB = LD(id, io), idC = LD(id, ie + 8), idD = LD(id, io + 8);
+        // steady state: the differences below - above of the lane's two columns once per stage (the rows do not change during it);
+        // a point's own column gives du71 / dw71, the neighbouring columns' differences - lane-shifted - give U4 / W4
+        constexpr int VPRE = EDGE ? 0 : 1;
+        double2 dU = {0.0, 0.0}, dW = {0.0, 0.0};
+        if (VPRE && !(FROM_ZERO && LO - jc == 0)) {   // (the first stage of a pass from zero has zero rows above and below)
+            dU.x = RD.u.x - RU.u.x; dU.y = RD.u.y - RU.u.y;
+            dW.x = RD.w.x - RU.w.x; dW.y = RD.w.y - RU.w.y;
+        }
         // diagonal blocks of the row's two points: the first sweep's stages store them, the later ones take them over
         constexpr int stg_dc = LO - jc;                                     // stage number
         constexpr int DCM = !DC ? 0 : (stg_dc < 2 ? 1 : 2);
@@ -344,14 +352,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
             Nbr n = {};       // (entries known to be zero are neither fetched nor read)
             double imv[9];
             bool gl = false, gr = false;
+            VDiff0 vd = {0.0, 0.0, 0.0, 0.0};
             if (par == 0) {   // even columns: left neighbour = odd column of lane - 1, right neighbour = the lane's odd column
                 if (needUD) {
                     n.u[1] = RU.u.x; n.w[1] = RU.w.x; n.g[1] = RU.g.x;
                     n.u[7] = RD.u.x; n.w[7] = RD.w.x; n.g[7] = RD.g.x;
-                    n.u[2] = RU.u.y; n.w[2] = RU.w.y;
-                    n.u[8] = RD.u.y; n.w[8] = RD.w.y;
-                    n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
-                    n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
+                    if (VPRE) {
+                        vd.du71 = dU.x; vd.dw71 = dW.x;
+                        vd.U4 = dU.y - lane_shr1(dU.y); vd.W4 = dW.y - lane_shr1(dW.y);
+                    } else {
+                        n.u[2] = RU.u.y; n.w[2] = RU.w.y;
+                        n.u[8] = RD.u.y; n.w[8] = RD.w.y;
+                        n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
+                        n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
+                    }
                 }
                 if (needLR) {
                     n.u[5] = RC.u.y; n.w[5] = RC.w.y; n.g[5] = RC.g.y;
@@ -366,10 +380,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                 if (needUD) {
                     n.u[1] = RU.u.y; n.w[1] = RU.w.y; n.g[1] = RU.g.y;
                     n.u[7] = RD.u.y; n.w[7] = RD.w.y; n.g[7] = RD.g.y;
-                    n.u[0] = RU.u.x; n.w[0] = RU.w.x;
-                    n.u[6] = RD.u.x; n.w[6] = RD.w.x;
-                    n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
-                    n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
+                    if (VPRE) {
+                        vd.du71 = dU.y; vd.dw71 = dW.y;
+                        vd.U4 = lane_shl1(dU.x) - dU.x; vd.W4 = lane_shl1(dW.x) - dW.x;
+                    } else {
+                        n.u[0] = RU.u.x; n.w[0] = RU.w.x;
+                        n.u[6] = RD.u.x; n.w[6] = RD.w.x;
+                        n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
+                        n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
+                    }
                 }
                 if (needLR) {
                     n.u[3] = RC.u.x; n.w[3] = RC.w.x; n.g[3] = RC.g.x;
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                     const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
                     gs0_point<true, Z, DCM>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm, &dg);
                 } else {
-                    gs0_point<false, Z, DCM>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm, &dg);
+                    gs0_point<false, Z, DCM, 1>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, inv_g, quirks, c0, c1, c2, u, w, gm, &dg, &vd);
                 }
             };
             if (ZM == 1) update(std::integral_constant<int, 1>{});
@@ -461,21 +480,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
             for (int v = 0; v < 3; ++v) dq[v] = *reinterpret_cast<const double2*>(dr + v * 1024);
         }
         double2 y[3];
+        constexpr int VPRE = EDGE ? 0 : 1;                                  // (see stage())
+        double2 dU = {0.0, 0.0}, dW = {0.0, 0.0};
+        if (VPRE) {
+            dU.x = RD.u.x - RU.u.x; dU.y = RD.u.y - RU.u.y;
+            dW.x = RD.w.x - RU.w.x; dW.y = RD.w.y - RU.w.y;
+        }
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             Nbr n;
             double imv[9];
             bool gl = false, gr = false;
+            VDiff0 vd = {0.0, 0.0, 0.0, 0.0};
             if (par == 0) {
                 n.u[1] = RU.u.x; n.w[1] = RU.w.x; n.g[1] = RU.g.x;
                 n.u[4] = RC.u.x; n.w[4] = RC.w.x; n.g[4] = RC.g.x;
                 n.u[7] = RD.u.x; n.w[7] = RD.w.x; n.g[7] = RD.g.x;
-                n.u[2] = RU.u.y; n.w[2] = RU.w.y;
                 n.u[5] = RC.u.y; n.w[5] = RC.w.y; n.g[5] = RC.g.y;
-                n.u[8] = RD.u.y; n.w[8] = RD.w.y;
-                n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
                 n.u[3] = lane_shr1(RC.u.y); n.w[3] = lane_shr1(RC.w.y); n.g[3] = lane_shr1(RC.g.y);
-                n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
+                if (VPRE) {
+                    vd.du71 = dU.x; vd.dw71 = dW.x;
+                    vd.U4 = dU.y - lane_shr1(dU.y); vd.W4 = dW.y - lane_shr1(dW.y);
+                } else {
+                    n.u[2] = RU.u.y; n.w[2] = RU.w.y;
+                    n.u[8] = RD.u.y; n.w[8] = RD.w.y;
+                    n.u[0] = lane_shr1(RU.u.y); n.w[0] = lane_shr1(RU.w.y);
+                    n.u[6] = lane_shr1(RD.u.y); n.w[6] = lane_shr1(RD.w.y);
+                }
                 if (BORDER && glE) {
                     gl = true;
                     n.u[0] = n.u[2]; n.w[0] = n.w[2]; n.u[3] = n.u[5]; n.w[3] = n.w[5]; n.g[3] = n.g[5]; n.u[6] = n.u[8]; n.w[6] = n.w[8];
@@ -485,12 +516,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                 n.u[1] = RU.u.y; n.w[1] = RU.w.y; n.g[1] = RU.g.y;
                 n.u[4] = RC.u.y; n.w[4] = RC.w.y; n.g[4] = RC.g.y;
                 n.u[7] = RD.u.y; n.w[7] = RD.w.y; n.g[7] = RD.g.y;
-                n.u[0] = RU.u.x; n.w[0] = RU.w.x;
                 n.u[3] = RC.u.x; n.w[3] = RC.w.x; n.g[3] = RC.g.x;
-                n.u[6] = RD.u.x; n.w[6] = RD.w.x;
-                n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
                 n.u[5] = lane_shl1(RC.u.x); n.w[5] = lane_shl1(RC.w.x); n.g[5] = lane_shl1(RC.g.x);
-                n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
+                if (VPRE) {
+                    vd.du71 = dU.y; vd.dw71 = dW.y;
+                    vd.U4 = lane_shl1(dU.x) - dU.x; vd.W4 = lane_shl1(dW.x) - dW.x;
+                } else {
+                    n.u[0] = RU.u.x; n.w[0] = RU.w.x;
+                    n.u[6] = RD.u.x; n.w[6] = RD.w.x;
+                    n.u[2] = lane_shl1(RU.u.x); n.w[2] = lane_shl1(RU.w.x);
+                    n.u[8] = lane_shl1(RD.u.x); n.w[8] = lane_shl1(RD.w.x);
+                }
                 if (BORDER && grO) {
                     gr = true;
                     n.u[2] = n.u[0]; n.w[2] = n.w[0]; n.u[5] = n.u[3]; n.w[5] = n.w[3]; n.g[5] = n.g[3]; n.u[8] = n.u[6]; n.w[8] = n.w[6];
@@ -507,7 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FROM_ZERO &
                 const double sDL = (oD && gl) ? 2.0 : 1.0, sDR = (oD && gr) ? 2.0 : 1.0;
                 apply0_point<true, DCT>(imv, n, sUL, sUR, sDL, sDR, alpha, beta, quirks, y0, y1, y2, &dg);
             } else {
-                apply0_point<false, DCT>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, quirks, y0, y1, y2, &dg);
+                apply0_point<false, DCT, 1>(imv, n, 1.0, 1.0, 1.0, 1.0, alpha, beta, quirks, y0, y1, y2, &dg, &vd);
             }
             if (par == 0) { y[0].x = y0; y[1].x = y1; y[2].x = y2; }
             else { y[0].y = y0; y[1].y = y1; y[2].y = y2; }
