@@ -136,11 +136,13 @@ def choose_pairs_in_flight(n_i, n_j, n_pairs, device=0, memory_fraction=0.6, cap
     return int(max(1, min(n_pairs, cap, budget // max(per_pair, 1))))
 
 
-def _float64_copy(a, n_threads=4):
+def _float64_copy(a, n_threads=4, wait=True):
     """``a.astype(np.float64)`` (always a copy, OF.py:769); stacks of more than 128 MB are converted by a few threads
-    (numpy copies release the GIL; the single-threaded copy of a 2 GB movie takes 0.16 s, a sixth of the whole call)."""
+    (numpy copies release the GIL; the single-threaded copy of a 2 GB movie takes 0.16 s, a sixth of the whole call).
+    ``wait=False``: returns ``(out, join)`` with the copy still running - ``join()`` waits for it."""
     if a.ndim < 1 or a.shape[0] < n_threads or a.size < (1 << 24):
-        return a.astype(np.float64)
+        out = a.astype(np.float64)
+        return out if wait else (out, lambda: None)
     out = np.empty(a.shape, dtype=np.float64)
     bounds = np.linspace(0, a.shape[0], n_threads + 1).astype(int)
 
@@ -149,9 +151,14 @@ def _float64_copy(a, n_threads=4):
     threads = [threading.Thread(target=work, args=(bounds[k], bounds[k + 1])) for k in range(n_threads)]
     for t in threads:
         t.start()
-    for t in threads:
-        t.join()
-    return out
+
+    def join():
+        for t in threads:
+            t.join()
+    if wait:
+        join()
+        return out
+    return out, join
 
 
 def _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
@@ -283,12 +290,22 @@ def variational_optical_flow(movie,
                                                 delta_x, delta_t, direct_fallback=bool(use_direct_solver and preconditioner is None))
     if output != "numpy":
         raise ValueError("output must be 'numpy' or 'torch'")
-    movie = _float64_copy(np.asarray(movie))                           # OF.py:769
-    if movie.ndim != 3:
+    source = np.asarray(movie)
+    if source.ndim != 3:
         raise ValueError("movie must be a 3-D array (frames, x, y)")
-    T, N_i, N_j = movie.shape
+    T, N_i, N_j = source.shape
     if T < 2:
         raise ValueError("movie needs at least two frames")
+    # OF.py:769: the reference works on (and returns, as 'original_data') a float64 COPY of the movie.  A stack that already is
+    # float64 and contiguous is only read by the solver, so the copy the result needs is made WHILE the solve runs (46 ms of a
+    # 0.39-s call at 1024 x 1024 x 256); anything else is converted first, as the reference does
+    if source.dtype == np.float64 and source.flags.c_contiguous:
+        movie, copy_done = _float64_copy(source, wait=False)
+        movie_in = source
+    else:
+        movie = _float64_copy(source)
+        copy_done = None
+        movie_in = movie
     params = _solver_params(speed_alpha, remodelling_alpha, delta_x, delta_t, initial_v_x, initial_v_y, initial_remodelling,
                             use_direct_solver, rtol, max_iterations, reference_quirks, coarse_precision, vcycle_precision,
                             multigrid_sweeps, w_cycle_level, krylov_method, gmres_restart, warm_start_stride, preconditioner)
@@ -297,19 +314,25 @@ def variational_optical_flow(movie,
         max_pairs_in_flight = choose_pairs_in_flight(N_i, N_j, T - 1, device, params=params)
     t0 = time.time()
     # a caller-owned context (_solver) or the module's cached one; blur and solve share it
-    with (contextlib.nullcontext(_solver) if _solver is not None
-          else _device_context(N_i, N_j, max_pairs_in_flight, device, exact)) as solver:
-        if smoothing_sigma is not None:                                 # OF.py:770-773
-            movie_to_analyse = blur_movie(movie, smoothing_sigma=smoothing_sigma, device=device, _solver=solver)
-        else:
-            movie_to_analyse = movie
-        try:
-            v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
-        except _native.VofError as exc:
-            if not (use_direct_solver and preconditioner is None and _direct_unavailable(exc)):
-                raise
-            params.preconditioner = 2        # too large for the direct preconditioner: multigrid to the same tight tolerance
-            v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+    try:
+        with (contextlib.nullcontext(_solver) if _solver is not None
+              else _device_context(N_i, N_j, max_pairs_in_flight, device, exact)) as solver:
+            if smoothing_sigma is not None:                                 # OF.py:770-773
+                movie_to_analyse = blur_movie(movie_in, smoothing_sigma=smoothing_sigma, device=device, _solver=solver)
+            else:
+                movie_to_analyse = movie_in
+            try:
+                v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+            except _native.VofError as exc:
+                if not (use_direct_solver and preconditioner is None and _direct_unavailable(exc)):
+                    raise
+                params.preconditioner = 2        # too large for the direct preconditioner: multigrid to the same tight tolerance
+                v_x, v_y, remodelling, speed, stats = solver.solve_host(np.ascontiguousarray(movie_to_analyse), params)
+    finally:
+        if copy_done is not None:
+            copy_done()
+    if smoothing_sigma is None:
+        movie_to_analyse = movie             # (the reference's 'blurred_data' is its float64 copy when nothing is blurred)
     if verbose:
         m, s, ms = format_elapsed_time(time.time() - t0)
         print(f"Elapsed time for solve: {m} minutes, {s} seconds, {ms} milliseconds")

@@ -114,6 +114,21 @@ def test_blur_path(of):
     assert res["original_data"].shape == g["movie"].shape
 
 
+def test_original_data_is_a_copy_made_while_the_solve_runs(of):
+    """OF.py:769: the reference works on movie.astype(float64) and returns that COPY as 'original_data' (and as 'blurred_data'
+    when nothing is blurred).  A float64 stack large enough for the threaded copy is read in place by the solver while the copy
+    is made in the background: the result must still hold an equal array that does not alias the caller's."""
+    movie = orc.make_texture_stack(640, 42, seed=3)                # 17.2 M values: above the threaded-copy threshold
+    keep = movie.copy()
+    res = of.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=1e4, return_stats=True)
+    assert res["stats"]["converged"].all()
+    assert np.array_equal(movie, keep)                              # the input is only read
+    assert res["original_data"] is not movie and not np.shares_memory(res["original_data"], movie)
+    assert np.array_equal(res["original_data"], movie) and res["blurred_data"] is res["original_data"]
+    res["original_data"][0, 0, 0] += 1.0
+    assert movie[0, 0, 0] == keep[0, 0, 0]
+
+
 def test_8bit_regime_uint8_input(of):
     """uint8 stack, alpha=1e4, beta=1e2 (the harder regime T of SURVEY Appendix B)."""
     g = load_golden("g6_8bit_64.npz")
