@@ -8,7 +8,7 @@ from opticalflow_amd.synthetic import texture_stack_numpy
 n, T = 1024, 256
 base = texture_stack_numpy(n, 17, seed=1)
 movie = np.concatenate([base] * 16)[:T].copy()
-for rep in range(3):
+for rep in range(int(os.environ.get("E2E_CALLS", "3"))):
     t0 = time.time()
     r = of.variational_optical_flow(movie, speed_alpha=1.0, remodelling_alpha=1e4, return_stats=True)
     dt = time.time() - t0
