@@ -399,7 +399,8 @@ def main():
             out["variants"]["time_varying_flow_wobble_0.3"] = timed(params, wob)
             out["variants"]["time_varying_flow_wobble_0.3_cold"] = timed(_native.default_params(vcycle_precision=vp, coarse_precision=cp, **cold), wob)
             del wob
-        if n_chunks == 1 and P >= 8:
+        free_now, _ = _native.device_memory(local_rank)
+        if n_chunks == 1 and P >= 8 and per_pair * (P + 2) < 0.8 * free_now:   # (beside the main context: 2048^2 x 128 does not fit twice)
             # two contexts, each with one half of the stack, on their own streams and host threads at the same time: the
             # instruction-bound passes of one half run over the bandwidth-bound kernels of the other.
             # Informational: per-launch times overlap in this mode, so the roofline figures above are taken with one context.
